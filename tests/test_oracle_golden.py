@@ -1,0 +1,172 @@
+"""Pins the CPU oracle (oracle/g2048_oracle.c) to vectors captured from the reference
+itself (tests/golden/*.npz, made by tests/golden/gen_golden.py). CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, tiles_of
+
+
+def test_rng_pin(oracle):
+    rows = load_golden("rng_pin.npz")["rows"]
+    for seed, dom, idx, ident, ctr, k0, k1, h in rows[:: 7]:
+        assert oracle.rng_keys(int(seed), int(dom), int(idx)) == (int(k0), int(k1))
+        assert oracle.rng_draw(int(k0), int(k1), int(ident), int(ctr)) == int(h)
+
+
+def test_draw_mapping(oracle):
+    assert oracle.draw_index(0xFFFFFFFF, 16) == 15
+    assert oracle.draw_index(0, 16) == 0
+    assert oracle.draw_index(0x8000FFFF, 2) == 1
+    assert not oracle.draw_is4(58981) and oracle.draw_is4(58982) and oracle.draw_is4(0xFFFF)
+    # 2-vs-4 rate and index uniformity of the hashed stream
+    k0, k1 = oracle.rng_keys(0x2048, oracle.DOM_STEP, 3)
+    hs = np.array([oracle.rng_draw(k0, k1, i, 0) for i in range(40000)], dtype=np.uint64)
+    rate4 = np.mean((hs & 0xFFFF) >= 58982)
+    assert abs(rate4 - 0.1) < 0.006
+    idx = ((hs >> 16) * 7) >> 16
+    cnt = np.bincount(idx.astype(int), minlength=7)
+    assert cnt.min() > 40000 / 7 * 0.93 and cnt.max() < 40000 / 7 * 1.07
+
+
+def test_row_slide_exhaustive(oracle):
+    """All 18^4 rows through env_move LEFT == the reference's _move_left."""
+    g = load_golden("row_slide.npz")
+    codes = np.array(np.meshgrid(*[np.arange(18)] * 4, indexing="ij")).reshape(4, -1).T.astype(np.uint8)
+    out, gain = g["out"], g["gain"]
+    for i in range(0, codes.shape[0], 4):
+        b, sc = oracle.env_move(tiles_of(codes[i:i + 4]).reshape(16), 0)
+        assert np.array_equal(b.reshape(4, 4), tiles_of(out[i:i + 4])), i
+        assert sc == int(gain[i:i + 4].sum()), i
+
+
+def test_step_transitions(oracle):
+    g = load_golden("step_transitions.npz")
+    n = g["board_in"].shape[0]
+    for i in range(n):
+        b, sc, r, d, v, hi = oracle.env_step(tiles_of(g["board_in"][i]), int(g["score_in"][i]),
+                                             int(g["action"][i]), int(g["h"][i]))
+        assert np.array_equal(b, tiles_of(g["board_out"][i])), i
+        assert sc == g["score_out"][i] and d == bool(g["done"][i]) and v == bool(g["valid"][i]), i
+        assert hi == g["highest_tile"][i], i
+        exp = g["reward"][i]
+        assert (np.isnan(exp) and np.isnan(r)) or r == exp, (i, r, exp)     # f64 bit-exact
+        assert int(g["consumed"][i]) == int(v), i
+
+
+def test_step_batch_matches_golden(oracle):
+    """The packed batched form (what the GPU is compared against at full size)."""
+    g = load_golden("step_transitions.npz")
+    n = g["board_in"].shape[0]
+    # re-key: batch form hashes its own draws, so feed boards whose recorded h equals the hashed one
+    k0, k1 = oracle.rng_keys(0x2048, oracle.DOM_STEP, 5)
+    assert all(oracle.rng_draw(k0, k1, i, 0) == int(g["h"][i]) for i in range(0, n, 97))
+    bo, sc, rw, fl = oracle.step_batch(g["board_in"], g["action"], g["score_in"].astype(np.uint32),
+                                       seed=0x2048, step_index=5, id_base=0)
+    assert np.array_equal(bo, g["board_out"])
+    assert np.array_equal(sc, g["score_out"].astype(np.uint32))
+    assert np.array_equal(rw, g["reward"], equal_nan=True)
+    assert np.array_equal(fl & 1, g["done"]) and np.array_equal((fl >> 1) & 1, g["valid"])
+    assert np.array_equal(fl >> 3, g["board_out"].max(axis=1))
+
+
+def test_moves_and_masks(oracle):
+    g = load_golden("moves.npz")
+    n = g["board"].shape[0]
+    for i in range(n):
+        t = tiles_of(g["board"][i])
+        assert oracle.env_valid_mask(t) == g["env_mask"][i], i
+        assert oracle.agent_valid_mask(t) == g["agent_mask"][i], i
+        for a in range(4):
+            b, sc, v = oracle.agent_move(t, a)
+            assert np.array_equal(b, tiles_of(g["agent_board"][i, a])), (i, a)
+            assert sc == g["agent_score"][i, a] and v == bool(g["agent_valid"][i, a]), (i, a)
+            b, sc = oracle.env_move(t, a)
+            assert np.array_equal(b, tiles_of(g["env_board"][i, a])) and sc == g["env_gain"][i, a], (i, a)
+    assert np.array_equal(oracle.valid_moves_batch(g["board"], False), g["env_mask"])
+    assert np.array_equal(oracle.valid_moves_batch(g["board"], True), g["agent_mask"])
+    # Q1: the agent's DOWN is rot180 of the env's DOWN
+    assert np.array_equal(g["agent_board"][:, 3, ::-1], g["env_board"][:, 3, :])
+    assert (g["env_mask"] != g["agent_mask"]).sum() > 0
+
+
+def test_eval_scores(oracle):
+    g = load_golden("eval_scores.npz")
+    b = g["board"]
+    assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_FAST), g["fast"])
+    for p in range(3):
+        ph = np.full(b.shape[0], p, np.uint8)
+        assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_FULL, ph), g["full"][:, p])       # f64 ==
+    assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_PPO), g["ppo_heuristic"])
+    for k in range(4):
+        assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_MONO_PP + k), g["monotonicity"][:, k])
+    assert np.array_equal(oracle.obs_batch(b).view(np.uint32), g["normalize"].view(np.uint32))   # f32 bits
+    for i in range(0, b.shape[0], 50):
+        t = tiles_of(b[i])
+        assert oracle.fast_eval(t) == g["fast"][i]
+        assert oracle.lib().g2048o_phase(int(t.max()), 512, 1024) == g["phase"][i]
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+def test_beam_decisions(oracle, explicit):
+    g = load_golden("beam_decisions.npz")
+    n = g["root"].shape[0]
+    seed, step_index = int(g["seed"]), int(g["step_index"])
+    k0, k1 = oracle.rng_keys(seed, oracle.DOM_BEAM, step_index)
+    for i in range(n):
+        w, d, gid = int(g["width"][i]), int(g["depth"][i]), int(g["game_id"][i])
+        draws = None
+        if explicit:
+            draws = np.array([oracle.rng_draw(k0, k1, gid, j) for j in range(int(g["consumed"][i]))], np.uint32)
+        res = oracle.beam_get_action(tiles_of(g["root"][i]), int(g["mask"][i]), w, d, draws=draws,
+                                     seed=seed, step_index=step_index, game_id=gid, trace_levels=30)
+        assert res["action"] == g["action"][i], i
+        assert res["prob"] == g["prob"][i], i
+        assert res["consumed"] == g["consumed"][i], i
+        nl = int(g["n_levels"][i])
+        assert np.array_equal(res["trace_counts"][:nl], g["trace_counts"][i][:nl]), i
+        for l in range(min(nl, 30)):
+            c = int(g["trace_counts"][i][l])
+            assert np.array_equal(res["trace_scores"][l, :c], g["trace_scores"][i][l, :c]), (i, l)   # f64 ==
+
+
+def test_beam_batch_matches_single(oracle):
+    g = load_golden("beam_decisions.npz")
+    sel = np.where((g["width"] == 20) & (g["mask"] < 0))[0][:40]
+    # batch form uses game_id_base + i, so compare against the single-call oracle with the same ids
+    act, prob, exp = oracle.beam_batch(g["root"][sel], 20, 30, seed=7, step_index=3, game_id_base=100)
+    for j, i in enumerate(sel):
+        r = oracle.beam_get_action(tiles_of(g["root"][i]), -1, 20, 30, seed=7, step_index=3, game_id=100 + j)
+        assert (act[j], prob[j], exp[j]) == (r["action"], np.float32(r["prob"]), r["expanded"])
+
+
+def test_episodes_replay(oracle):
+    g = load_golden("episodes.npz")
+    for e in range(4):
+        b = oracle.env_reset(int(g["ep%d_reset_h" % e][0]), int(g["ep%d_reset_h" % e][1]))
+        assert np.array_equal(b, tiles_of(g["ep%d_board0" % e]))
+        score, hi = 0, int(b.max())
+        for t in range(g["ep%d_action" % e].shape[0]):
+            b, score, r, d, v, hi = oracle.env_step(b, score, int(g["ep%d_action" % e][t]),
+                                                    int(g["ep%d_h" % e][t]), highest_tile=hi)
+            assert np.array_equal(b, tiles_of(g["ep%d_board" % e][t])), (e, t)
+            assert r == g["ep%d_reward" % e][t] and d == bool(g["ep%d_done" % e][t]), (e, t)
+            assert score == g["ep%d_score" % e][t] and v == bool(g["ep%d_valid" % e][t]), (e, t)
+            assert hi == int(b.max())          # Q2: highest_tile always equals max(board) after a step
+        assert d
+
+
+def test_config1_trace_batch_schedule(oracle):
+    """Config 1: 1 board, reset, 1000 hashed actions, auto-reset -- through the batched oracle
+    with the product's draw schedule; must equal what the reference did."""
+    g = load_golden("episodes.npz")
+    seed = int(g["seed"])
+    b, sc = oracle.reset_batch(1, seed=seed, epoch=0, id_base=0)
+    assert np.array_equal(b[0], g["c1_board0"])
+    for t in range(1000):
+        a = oracle.synth_actions(1, seed=seed, step_index=t, id_base=0)
+        assert a[0] == g["c1_action"][t]
+        b, sc, rw, fl = oracle.step_batch(b, a, sc, seed=seed, step_index=t, id_base=0, opts=1)
+        assert np.array_equal(b[0], g["c1_board"][t]), t
+        assert rw[0] == g["c1_reward"][t] and (fl[0] & 1) == g["c1_done"][t], t
+        exp_score = 0 if g["c1_done"][t] else g["c1_score"][t]
+        assert sc[0] == exp_score, t
