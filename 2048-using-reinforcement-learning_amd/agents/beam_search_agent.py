@@ -1,0 +1,81 @@
+"""Drop-in for the reference's agents/beam_search_agent.py: same class name, constructor, get_action
+contract, no-op remember/update, JSON save/load. The search itself runs on the GPU
+(`g2048_beam_get_action`, one wavefront per game); for many games at once use
+`g2048.BatchedBeamSearch`. The reference's quirks are reproduced by default (its DOWN move returns the
+180-degree-rotated board; the phase is fixed from the root) -- see DESIGN.md."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from g2048 import _lib as L
+from g2048 import ops
+
+
+class BeamSearchAgent:
+    def __init__(self, beam_width=10, search_depth=15, seed=None, device="cuda"):      # reference :13-30
+        if not (1 <= int(beam_width) <= L.BEAM_MAX_WIDTH):
+            raise ValueError("BeamSearchAgent: beam_width must be in 1..%d on the MI355X engine" % L.BEAM_MAX_WIDTH)
+        self.beam_width = beam_width
+        self.search_depth = search_depth
+        self.action_names = {0: "LEFT", 1: "UP", 2: "RIGHT", 3: "DOWN"}
+        self.early_game_threshold = 512
+        self.mid_game_threshold = 1024
+        self.device = torch.device(device)
+        self.seed = random.getrandbits(63) if seed is None else int(seed)
+        self._calls = 0
+
+    def get_action(self, state, valid_moves=None):                                      # reference :71-181
+        if self.device.type != "cuda":
+            raise RuntimeError("BeamSearchAgent: needs a ROCm device; there is no CPU path")
+        tiles = torch.as_tensor(np.ascontiguousarray(state, dtype=np.int32).reshape(1, 16), device=self.device)
+        roots = ops.pack(tiles)
+        mask = None
+        if valid_moves is not None:
+            m = sum(int(bool(v)) << a for a, v in enumerate(list(valid_moves)[:4]))
+            mask = torch.tensor([m], dtype=torch.uint8, device=self.device)
+        actions, probs = ops.beam_get_action(roots, self.beam_width, self.search_depth, mask,
+                                             self.early_game_threshold, self.mid_game_threshold,
+                                             self.seed, self._calls, 0)
+        self._calls += 1
+        return int(actions.item()), float(probs.item())
+
+    def remember(self, *args):                                                          # reference :405-407
+        pass
+
+    def update(self):                                                                   # reference :409-411
+        pass
+
+    def save(self, path):                                                               # reference :413-449
+        config = {
+            "beam_width": self.beam_width,
+            "search_depth": self.search_depth,
+            "early_game_threshold": self.early_game_threshold,
+            "mid_game_threshold": self.mid_game_threshold,
+        }
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(config, f, indent=4)
+        print(f"Beam Search configuration saved to {path}")
+        readme_path = os.path.join(os.path.dirname(path),
+                                   f"beam_search_config_readme_{self.beam_width}_{self.search_depth}.txt")
+        with open(readme_path, "w") as f:
+            f.write("Beam Search Agent Configuration\n==============================\n\n")
+            f.write(f"Beam Width: {self.beam_width}\nSearch Depth: {self.search_depth}\n")
+            f.write(f"Early Game Threshold: {self.early_game_threshold}\nMid Game Threshold: {self.mid_game_threshold}\n")
+            f.write(f"\nSaved at: {path}\n")
+            f.write(f"agent = BeamSearchAgent(beam_width={self.beam_width}, search_depth={self.search_depth})")
+
+    @classmethod
+    def load(cls, path):                                                                # reference :451-478
+        with open(path, "r") as f:
+            config = json.load(f)
+        agent = cls(beam_width=config.get("beam_width", 10), search_depth=config.get("search_depth", 15))
+        if "early_game_threshold" in config:
+            agent.early_game_threshold = config["early_game_threshold"]
+        if "mid_game_threshold" in config:
+            agent.mid_game_threshold = config["mid_game_threshold"]
+        print(f"Beam Search configuration loaded from {path}")
+        return agent

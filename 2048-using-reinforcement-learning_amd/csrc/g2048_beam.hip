@@ -1,0 +1,198 @@
+// g2048_beam.hip -- BeamSearchAgent.get_action (reference agents/beam_search_agent.py:71-181) on gfx950.
+//
+// One wavefront owns one game. The beam (<= 32 boards, 16 B each) lives in LDS; at every level the
+// 4 * beam children map onto the 64 lanes (two passes when 4 * width > 64), each lane doing one
+// agent move (g2048_board.h, the same SWAR code the env kernel uses), its validity, the spawn and
+// the heuristic score in registers. The only cross-lane steps are
+//   * the draw index: the reference consumes its RNG sequentially in generation order
+//     (parent rank, then action); a child's position in that sequence is a ballot prefix count,
+//     so the j-th generated child of a decision always gets draw j, exactly as the Python loop does;
+//   * the top-k compaction: each candidate counts the candidates that sort before it
+//     (score descending, generation order ascending = Python's stable sorted(reverse=True)) with
+//     broadcast LDS reads of the score array, and the first `width` write themselves back to the
+//     beam at their rank.
+// Scores are f64 in the reference's operation order (bit-exact with the oracle); no MFMA, no global
+// memory traffic inside the search (root in, action out).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/g2048.h"
+#include "g2048_board.h"
+#include "g2048_rng.h"
+
+using namespace g2048;
+
+namespace {
+
+constexpr int kMaxWidth = G2048_BEAM_MAX_WIDTH;
+
+__device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ roots, const uint8_t *__restrict__ mask_in,
+                                                 uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
+                                                 uint32_t *__restrict__ expanded_out, int width, int depth,
+                                                 uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
+                                                 uint64_t id_base, bool fixed_down)
+{
+    __shared__ uint4 s_board[kMaxWidth];
+    __shared__ uint32_t s_root[kMaxWidth];
+    __shared__ __align__(16) double s_score[64 * PASSES];
+
+    const uint32_t lane = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const uint64_t gid = id_base + g;
+    const uint4 rv = roots[g];
+    const Board root = {{rv.x, rv.y, rv.z, rv.w}};
+
+    // :82-93 -- caller mask or the agent's own validity; 0 or 1 valid move short-circuit
+    const uint32_t mask = mask_in ? (uint32_t)(mask_in[g] & 15u) : valid_mask_agent(root, fixed_down);
+    const uint32_t nvalid = popc(mask);
+    if (nvalid <= 1u) {
+        if (lane == 0) {
+            action_out[g] = nvalid ? (uint8_t)__builtin_ctz(mask) : (uint8_t)0;
+            prob_out[g] = nvalid ? 1.0f : 0.5f;
+            if (expanded_out) expanded_out[g] = 0u;
+        }
+        return;
+    }
+    // :96-106 -- phase and depth are fixed from the ROOT board
+    const uint32_t phase = phase_of(max_code(root), early_thr, mid_thr);
+    const uint32_t root_empty = count_empty(root);
+    int actual_depth;
+    if (root_empty <= 4u) actual_depth = min(depth + 5, 25);
+    else if (root_empty >= 10u) actual_depth = min(depth - 5, 10);
+    else actual_depth = depth;
+
+    int nb = 0;                    // current beam size
+    uint32_t draws = 0, expanded = 0;
+
+    for (int level = 0; level == 0 || level < actual_depth; ++level) {
+        const int nslots = level == 0 ? 4 : 4 * nb;
+        const bool fast = level == 0 || level > 3;             // :122, :139
+        Board child[PASSES];
+        double score[PASSES];
+        bool ok[PASSES];
+        uint32_t ract[PASSES];
+        uint32_t total_valid = 0;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 64 + (int)lane;
+            bool enabled = slot < nslots;
+            const uint32_t a = (uint32_t)slot & 3u;
+            Board P = root;
+            uint32_t ra = a;
+            if (level == 0) {
+                enabled = enabled && ((mask >> a) & 1u);
+            } else if (enabled) {
+                const uint4 pv = s_board[slot >> 2];
+                P = Board{{pv.x, pv.y, pv.z, pv.w}};
+                ra = s_root[slot >> 2];
+            }
+            uint32_t gain;
+            Board c = move_agent(P, a, gain, fixed_down);                       // :115 / :152
+            const bool v = enabled && !same(c, P);
+            const bool consume = v && count_empty(c) != 0u;                      // :262-263
+            const unsigned long long bc = __ballot(consume);
+            const uint32_t j = draws + prefix_count(bc);                         // generation order
+            draws += (uint32_t)__popcll(bc);
+            {
+                Board s = c;
+                spawn(s, rng_draw(k0, k1, gid, j));                              // :118 / :155
+                c.w[0] = consume ? s.w[0] : c.w[0]; c.w[1] = consume ? s.w[1] : c.w[1];
+                c.w[2] = consume ? s.w[2] : c.w[2]; c.w[3] = consume ? s.w[3] : c.w[3];
+            }
+            const double sc = fast ? eval_fast(c) : eval_full(c, phase);        // :122 / :158-161
+            const unsigned long long bv = __ballot(v);
+            total_valid += (uint32_t)__popcll(bv);
+            s_score[slot] = v ? sc : -INFINITY;
+            child[p] = c; score[p] = sc; ok[p] = v; ract[p] = ra;
+        }
+        expanded += total_valid;
+        if (total_valid == 0u) {
+            if (level == 0) {                                                   // :126-128 random valid action, prob 0.5
+                if (lane == 0) {
+                    uint32_t idx = ((rng_draw(k0, k1, gid, draws) >> 16) * nvalid) >> 16;
+                    uint32_t m = mask;
+                    while (idx--) m &= m - 1u;
+                    action_out[g] = (uint8_t)__builtin_ctz(m);
+                    prob_out[g] = 0.5f;
+                    if (expanded_out) expanded_out[g] = 0u;
+                }
+                return;
+            }
+            break;                                                              // :170-171 keep the previous beam
+        }
+        __syncthreads();
+        // stable descending rank of every valid candidate (:131, :174)
+        uint32_t rank[PASSES];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) rank[p] = 0u;
+        for (int j = 0; j < nslots; j += 2) {
+            const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int slot = p * 64 + (int)lane;
+                rank[p] += (sj.x > score[p] || (sj.x == score[p] && j < slot)) ? 1u : 0u;
+                rank[p] += (sj.y > score[p] || (sj.y == score[p] && j + 1 < slot)) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            if (ok[p] && rank[p] < (uint32_t)width) {                            // :132 / :175
+                s_board[rank[p]] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
+                s_root[rank[p]] = ract[p];
+            }
+        }
+        nb = (int)min(total_valid, (uint32_t)width);
+        __syncthreads();
+    }
+    if (lane == 0) {                                                            // :178-181
+        action_out[g] = (uint8_t)s_root[0];
+        prob_out[g] = 1.0f;
+        if (expanded_out) expanded_out[g] = expanded;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// defined in g2048_kernels.hip; the beam entry point reports through the same thread-local string
+const char *g2048_last_error(void);
+void g2048_set_last_error_(const char *msg);
+
+int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                          float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                          int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                          uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+{
+    if (n_games == 0) return G2048_OK;
+    if (!root_boards || !action_out || !prob_out) { g2048_set_last_error_("g2048_beam_get_action: null pointer"); return G2048_ERR_ARG; }
+    if (reinterpret_cast<uintptr_t>(root_boards) & 15u) { g2048_set_last_error_("g2048_beam_get_action: root array must be 16-byte aligned"); return G2048_ERR_ARG; }
+    if (width < 1 || width > kMaxWidth) { g2048_set_last_error_("g2048_beam_get_action: width must be in 1..32"); return G2048_ERR_ARG; }
+    if (opts & ~G2048_BEAM_FIXED_DOWN) { g2048_set_last_error_("g2048_beam_get_action: unknown opts"); return G2048_ERR_ARG; }
+    if (n_games > 0x7fffffffu) { g2048_set_last_error_("g2048_beam_get_action: too many games for one launch"); return G2048_ERR_ARG; }
+    if (early_threshold < 0 || mid_threshold < 0) { g2048_set_last_error_("g2048_beam_get_action: negative threshold"); return G2048_ERR_ARG; }
+    const Keys k = rng_keys(seed, DOM_BEAM, step_index);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)n_games), block(64);
+    const uint4 *roots = static_cast<const uint4 *>(root_boards);
+    const bool fd = (opts & G2048_BEAM_FIXED_DOWN) != 0;
+    if (4 * width <= 64)
+        hipLaunchKernelGGL(beam_kernel<1>, grid, block, 0, s, roots, valid_mask_or_null, action_out, prob_out,
+                           expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold,
+                           k.k0, k.k1, game_id_base, fd);
+    else
+        hipLaunchKernelGGL(beam_kernel<2>, grid, block, 0, s, roots, valid_mask_or_null, action_out, prob_out,
+                           expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold,
+                           k.k0, k.k1, game_id_base, fd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+    return G2048_OK;
+}
+
+}  // extern "C"

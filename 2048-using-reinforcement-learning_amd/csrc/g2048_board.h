@@ -1,0 +1,531 @@
+// g2048_board.h -- per-board 2048 arithmetic for CDNA4 (gfx950), one board per lane.
+//
+// A board is 16 x uint8 log2 codes (0 = empty, k = tile 2^k, k <= 17), row-major,
+// held in four 32-bit VGPRs: w[r] = row r, cell (r,c) in bits [8c, 8c+8). One
+// global_load_dwordx4 brings a board in; everything below is SWAR over those
+// four registers -- byte lanes never carry into each other because codes stay
+// < 0x40.
+//
+// The slide is done for all four lines of a direction at once: with the four
+// row words w[0..3], byte lane c of the words IS column c, so "slide UP" is a
+// byte-lane-parallel compaction + merge across the four words. LEFT/RIGHT run
+// on the 4x4 byte transpose (8 v_perm_b32), DOWN/RIGHT on the reversed word
+// order, so one code path serves all four actions and lanes of a wave never
+// diverge on the action.
+//
+// What each routine implements (reference file:line) is stated at the routine.
+// Functions are __host__ __device__ so tests/hostsim can unit-test this exact
+// arithmetic on a CPU against the oracle; the product library only ever calls
+// them from kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define G2048_HD __host__ __device__ __forceinline__
+#else
+#define G2048_HD inline
+#endif
+
+namespace g2048 {
+
+struct Board { uint32_t w[4]; };
+
+constexpr uint32_t B80 = 0x80808080u;
+constexpr uint32_t B7F = 0x7f7f7f7fu;
+
+// RNG domains (DESIGN.md "RNG")
+enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6 };
+
+// ---------------------------------------------------------------- intrinsics --
+// v_perm_b32: bytes of {s0:s1} (s1 = bytes 0..3, s0 = bytes 4..7) picked by the
+// selector bytes; selector 0x0c yields 0x00.
+G2048_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+    uint64_t v = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) {
+        uint32_t b = (sel >> (8 * k)) & 0xffu;
+        uint32_t byte = b < 8 ? (uint32_t)(v >> (8 * b)) & 0xffu : (b == 12 ? 0u : 0xffu);
+        r |= byte << (8 * k);
+    }
+    return r;
+#endif
+}
+
+G2048_HD uint32_t popc(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_popcount(x);
+#else
+    return (uint32_t)__builtin_popcount(x);
+#endif
+}
+
+// sum over the 4 bytes of a[i]*b[i] + c  (v_dot4_u32_u8)
+G2048_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+    return c;
+#endif
+}
+
+// ------------------------------------------------------------------- flags ----
+// 0x80 in every byte lane that is non-zero / zero.
+G2048_HD uint32_t nzflag(uint32_t x) { return (x + B7F) & B80; }
+G2048_HD uint32_t zflag(uint32_t x) { return ~(x + B7F) & B80; }
+// 0x80 where x == y and x != 0
+G2048_HD uint32_t eqnzflag(uint32_t x, uint32_t y) { return (x + B7F) & ~((x ^ y) + B7F) & B80; }
+// 0x80 where x >= y (bytes < 0x80)
+G2048_HD uint32_t geflag(uint32_t x, uint32_t y) { return ((x | B80) - y) & B80; }
+// v_perm selector: byte lanes with the flag take s0's byte, the others s1's
+G2048_HD uint32_t selof(uint32_t flag) { return 0x03020100u + (flag >> 5); }
+G2048_HD uint32_t pick(uint32_t if_flag, uint32_t otherwise, uint32_t sel) { return perm(if_flag, otherwise, sel); }
+
+G2048_HD uint32_t count_empty(const Board &b)
+{
+    return popc(zflag(b.w[0])) + popc(zflag(b.w[1])) + popc(zflag(b.w[2])) + popc(zflag(b.w[3]));
+}
+
+G2048_HD bool same(const Board &a, const Board &b)
+{
+    return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) == 0;
+}
+
+// 4x4 byte transpose: 2 x 4 v_perm_b32
+G2048_HD Board transpose(const Board &b)
+{
+    uint32_t t0 = perm(b.w[1], b.w[0], 0x05010400u);   // r0.0 r1.0 r0.1 r1.1
+    uint32_t t1 = perm(b.w[1], b.w[0], 0x07030602u);   // r0.2 r1.2 r0.3 r1.3
+    uint32_t t2 = perm(b.w[3], b.w[2], 0x05010400u);   // r2.0 r3.0 r2.1 r3.1
+    uint32_t t3 = perm(b.w[3], b.w[2], 0x07030602u);   // r2.2 r3.2 r2.3 r3.3
+    Board o;
+    o.w[0] = perm(t2, t0, 0x05040100u);                // r0.0 r1.0 r2.0 r3.0
+    o.w[1] = perm(t2, t0, 0x07060302u);                // r0.1 r1.1 r2.1 r3.1
+    o.w[2] = perm(t3, t1, 0x05040100u);
+    o.w[3] = perm(t3, t1, 0x07060302u);
+    return o;
+}
+
+G2048_HD Board rot180(const Board &b)
+{
+    Board o;
+    o.w[0] = perm(0u, b.w[3], 0x00010203u);
+    o.w[1] = perm(0u, b.w[2], 0x00010203u);
+    o.w[2] = perm(0u, b.w[1], 0x00010203u);
+    o.w[3] = perm(0u, b.w[0], 0x00010203u);
+    return o;
+}
+
+// ------------------------------------------------------------------- slide ----
+// The reference's row rule (environment/game_2048.py:116-168, identically
+// agents/beam_search_agent.py:213-242): drop zeros, scan toward the far end,
+// equal neighbours merge once into code+1 (score += 2^(code+1)), pad with zeros.
+// Here: L[k] holds position k of four independent lines (one per byte lane),
+// sliding toward k = 0. Returns the score gained by all four lines.
+G2048_HD uint32_t slide_lines(uint32_t L[4])
+{
+    // compaction: three stages, stage k closes a hole at position k
+    {
+        uint32_t s = selof(nzflag(L[2]));
+        L[2] = pick(L[2], L[3], s);
+        L[3] = pick(L[3], 0u, s);
+        s = selof(nzflag(L[1]));
+        L[1] = pick(L[1], L[2], s);
+        L[2] = pick(L[2], L[3], s);
+        L[3] = pick(L[3], 0u, s);
+        s = selof(nzflag(L[0]));
+        L[0] = pick(L[0], L[1], s);
+        L[1] = pick(L[1], L[2], s);
+        L[2] = pick(L[2], L[3], s);
+        L[3] = pick(L[3], 0u, s);
+    }
+    const uint32_t A = L[0], B = L[1], C = L[2], D = L[3];
+    // merge decisions, scanning from position 0: a tile merges at most once
+    const uint32_t m01 = eqnzflag(A, B);
+    const uint32_t m12 = eqnzflag(B, C) & ~m01;
+    const uint32_t m23 = eqnzflag(C, D) & ~m12;
+    const uint32_t s01 = selof(m01), s12 = selof(m12), s23 = selof(m23);
+    const uint32_t Cp = C + (m23 >> 7);
+    const uint32_t o0 = A + (m01 >> 7);
+    const uint32_t o1 = pick(Cp, B + (m12 >> 7), s01);
+    const uint32_t o2 = pick(pick(0u, D, s23), pick(D, Cp, s12), s01);
+    const uint32_t o3 = pick(0u, D, selof(m01 | m12 | m23));
+    L[0] = o0; L[1] = o1; L[2] = o2; L[3] = o3;
+    // score: merged tiles sit in o0 (m01), o1 (m01&m23 | m12), o2 (m23 & ~m01)
+    const uint32_t g1 = (m01 & m23) | m12, g2 = m23 & ~m01;
+    const uint32_t any = m01 | g1 | g2;
+    uint32_t gain = 0;
+    if (any) {      // wave-level skip when no lane merged anything (cheap, common late in dense boards)
+        const uint32_t G0 = pick(o0, 0u, s01), G1 = pick(o1, 0u, selof(g1)), G2 = pick(o2, 0u, selof(g2));
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc += (1u << ((G0 >> (8 * k)) & 0xffu)) + (1u << ((G1 >> (8 * k)) & 0xffu)) + (1u << ((G2 >> (8 * k)) & 0xffu));
+        }
+        // every non-merged byte contributed 1<<0
+        gain = acc - (12u - popc(m01) - popc(g1) - popc(g2));
+    }
+    return gain;
+}
+
+// One move on the whole board. action: 0 LEFT, 1 UP, 2 RIGHT, 3 DOWN
+// (environment/game_2048.py:11-16). Env semantics (:97-114).
+G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
+{
+    const bool horiz = (action & 1u) == 0u;
+    const bool rev = (action & 2u) != 0u;
+    const Board t = transpose(b);
+    uint32_t L[4];
+    {
+        const uint32_t x0 = horiz ? t.w[0] : b.w[0], x1 = horiz ? t.w[1] : b.w[1];
+        const uint32_t x2 = horiz ? t.w[2] : b.w[2], x3 = horiz ? t.w[3] : b.w[3];
+        L[0] = rev ? x3 : x0; L[1] = rev ? x2 : x1; L[2] = rev ? x1 : x2; L[3] = rev ? x0 : x3;
+    }
+    gain = slide_lines(L);
+    Board v;
+    v.w[0] = rev ? L[3] : L[0]; v.w[1] = rev ? L[2] : L[1]; v.w[2] = rev ? L[1] : L[2]; v.w[3] = rev ? L[0] : L[3];
+    const Board vt = transpose(v);
+    Board o;
+    o.w[0] = horiz ? vt.w[0] : v.w[0]; o.w[1] = horiz ? vt.w[1] : v.w[1];
+    o.w[2] = horiz ? vt.w[2] : v.w[2]; o.w[3] = horiz ? vt.w[3] : v.w[3];
+    return o;
+}
+
+// BeamSearchAgent._make_move (agents/beam_search_agent.py:194-258): LEFT/UP/RIGHT
+// as the env; DOWN returns rot180 of the true result because the post-transform
+// (:252-253) is not the inverse of the pre-transform (:210). `fixed_down` turns
+// the quirk off (non-parity option).
+G2048_HD Board move_agent(const Board &b, uint32_t action, uint32_t &gain, bool fixed_down)
+{
+    Board o = move_env(b, action, gain);
+    const bool quirk = (action == 3u) && !fixed_down;
+    const Board r = rot180(o);
+    o.w[0] = quirk ? r.w[0] : o.w[0]; o.w[1] = quirk ? r.w[1] : o.w[1];
+    o.w[2] = quirk ? r.w[2] : o.w[2]; o.w[3] = quirk ? r.w[3] : o.w[3];
+    return o;
+}
+
+// Game2048Env.get_valid_moves (environment/game_2048.py:69-95) without moving:
+// a direction is valid iff some line has a tile with an empty cell further along
+// the direction, or two equal neighbours. Bit a = action a.
+G2048_HD uint32_t valid_mask_env(const Board &b)
+{
+    const uint32_t n0 = nzflag(b.w[0]), n1 = nzflag(b.w[1]), n2 = nzflag(b.w[2]), n3 = nzflag(b.w[3]);
+    const uint32_t z0 = n0 ^ B80, z1 = n1 ^ B80, z2 = n2 ^ B80, z3 = n3 ^ B80;
+    // vertical: byte lane = column
+    const uint32_t up = (z0 & (n1 | n2 | n3)) | (z1 & (n2 | n3)) | (z2 & n3);
+    const uint32_t down = (z3 & (n2 | n1 | n0)) | (z2 & (n1 | n0)) | (z1 & n0);
+    const uint32_t pv = eqnzflag(b.w[0], b.w[1]) | eqnzflag(b.w[1], b.w[2]) | eqnzflag(b.w[2], b.w[3]);
+    // horizontal: within a word; cell c at byte c
+    uint32_t left = 0, right = 0, ph = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t n = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
+        const uint32_t z = n ^ B80;
+        left |= z & ((n >> 8) | (n >> 16) | (n >> 24));      // empty with a tile at a higher column
+        right |= z & ((n << 8) | (n << 16) | (n << 24));     // empty with a tile at a lower column
+        ph |= eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u;
+    }
+    return ((left | ph) ? 1u : 0u) | ((up | pv) ? 2u : 0u) | ((right | ph) ? 4u : 0u) | ((down | pv) ? 8u : 0u);
+}
+
+// BeamSearchAgent._check_valid_moves (agents/beam_search_agent.py:183-192):
+// LEFT/UP/RIGHT agree with the env; DOWN compares rot180(true DOWN) with the board.
+G2048_HD uint32_t valid_mask_agent(const Board &b, bool fixed_down)
+{
+    uint32_t m = valid_mask_env(b);
+    if (!fixed_down) {
+        uint32_t g;
+        const Board d = move_agent(b, 3u, g, false);
+        m = (m & 7u) | (same(d, b) ? 0u : 8u);
+    }
+    return m;
+}
+
+// true iff no move changes the board (environment/game_2048.py:279-288)
+G2048_HD bool game_over(const Board &b) { return valid_mask_env(b) == 0u; }
+
+// ------------------------------------------------------------------- spawn ----
+// add_new_tile (environment/game_2048.py:59-67) / _add_random_tile
+// (agents/beam_search_agent.py:260-269): the idx-th empty cell in row-major
+// order gets a 2 (code 1) or a 4 (code 2). h is one 32-bit draw:
+// idx = ((h >> 16) * n_empty) >> 16, four iff (h & 0xffff) >= 58982.
+// No-op on a full board. Returns n_empty before the spawn.
+G2048_HD uint32_t spawn(Board &b, uint32_t h)
+{
+    const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
+    const uint32_t c0 = popc(z0), c1 = c0 + popc(z1), c2 = c1 + popc(z2), n = c2 + popc(z3);
+    const uint32_t idx = ((h >> 16) * n) >> 16;
+    const uint32_t row = (idx >= c0 ? 1u : 0u) + (idx >= c1 ? 1u : 0u) + (idx >= c2 ? 1u : 0u);
+    uint32_t z = row == 0 ? z0 : row == 1 ? z1 : row == 2 ? z2 : z3;
+    const uint32_t k = idx - (row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c1 : c2);
+    z &= z - (k > 0 ? 1u : 0u);         // drop the k lowest set flags (z != 0 whenever n != 0)
+    z &= z - (k > 1 ? 1u : 0u);
+    z &= z - (k > 2 ? 1u : 0u);
+    const uint32_t bit = z & (0u - z);  // 0x80 << 8c of the chosen cell (0 when the board is full)
+    const uint32_t add = (n == 0u) ? 0u : bit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
+    b.w[0] |= row == 0 ? add : 0u; b.w[1] |= row == 1 ? add : 0u;
+    b.w[2] |= row == 2 ? add : 0u; b.w[3] |= row == 3 ? add : 0u;
+    return n;
+}
+
+// reset (environment/game_2048.py:29-48): empty board, two spawns
+G2048_HD Board fresh_board(uint32_t h0, uint32_t h1)
+{
+    Board b = {{0u, 0u, 0u, 0u}};
+    spawn(b, h0);
+    spawn(b, h1);
+    return b;
+}
+
+// ----------------------------------------------------------------- RNG --------
+// draw(k0, k1, id, ctr): two xorshift-multiply finalizers; (k0, k1) are derived
+// on the host from (seed, domain, index) (g2048_rng.h). Restated independently
+// in oracle/g2048_oracle.c.
+G2048_HD uint32_t rng_draw(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr)
+{
+    uint32_t h = (uint32_t)id ^ k0;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += k1 + (uint32_t)(id >> 32) * 0x9E3779B1u + ctr * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+// --------------------------------------------------------------- tile sums ----
+struct TileStats {
+    uint32_t total;      // sum of tile values
+    uint32_t edge;       // row0 + row3 + col0 + col3 (corners twice)  (game_2048.py:254-256)
+    uint32_t orbits;     // OR of (1 << code) over all cells (bit 0 set iff any empty)
+};
+
+G2048_HD TileStats tile_stats(const Board &b)
+{
+    uint32_t rs[4], outer = 0, orb = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t x = b.w[r];
+        const uint32_t t0 = 1u << (x & 0xffu), t1 = 1u << ((x >> 8) & 0xffu);
+        const uint32_t t2 = 1u << ((x >> 16) & 0xffu), t3 = 1u << (x >> 24);
+        rs[r] = t0 + t1 + t2 + t3;
+        outer += t0 + t3;
+        orb |= t0 | t1 | t2 | t3;
+    }
+    // empty cells contributed 1 each: subtract their counts
+    const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
+    const uint32_t zall = popc(z0) + popc(z1) + popc(z2) + popc(z3);
+    const uint32_t zcols = popc((z0 | (z1 >> 1) | (z2 >> 2) | (z3 >> 3)) & 0xf00000f0u);  // col 0 and col 3 flags of 4 rows
+    TileStats s;
+    s.total = rs[0] + rs[1] + rs[2] + rs[3] - zall;
+    s.edge = rs[0] + rs[3] + outer - popc(z0) - popc(z3) - zcols;
+    s.orbits = orb;
+    return s;
+}
+
+G2048_HD uint32_t max_code(const Board &b)
+{
+    const TileStats s = tile_stats(b);
+    return 31u - (uint32_t)__builtin_clz(s.orbits | 1u);
+}
+
+// ----------------------------------------------------------------- reward -----
+// Game2048Env._calculate_reward (environment/game_2048.py:212-277) in the
+// reference's f64 operation order. The milestone branch (:229-241) compares the
+// env's highest_tile -- not yet updated when the reward is computed (:195 vs
+// :200-203) -- with max(prev_board); the two are always equal inside step(), so
+// the branch is dead there and is not generated. `cur` is the post-spawn board.
+// Must be compiled with -ffp-contract=off (the 0.1 terms are mul THEN add).
+G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
+                           uint32_t empty_before, uint32_t empty_after)
+{
+    double r = (double)gain / 4.0;
+    if (!valid) r -= 2.0;
+    r += (double)((int)empty_after - (int)empty_before) * 0.5;
+    r += ((double)st.edge / (double)st.total) * 1.0;
+    if (empty_after <= 2u) r -= 2.0;
+    // ordered pairs (:267-275): row i pairs (j-1, j) with both > 0 and x[j] >= x[j-1]; same for col i
+    const uint32_t n0 = nzflag(cur.w[0]), n1 = nzflag(cur.w[1]), n2 = nzflag(cur.w[2]), n3 = nzflag(cur.w[3]);
+    const uint32_t v01 = geflag(cur.w[1], cur.w[0]) & n0 & n1;
+    const uint32_t v12 = geflag(cur.w[2], cur.w[1]) & n1 & n2;
+    const uint32_t v23 = geflag(cur.w[3], cur.w[2]) & n2 & n3;
+    const uint32_t colcnt = (v01 >> 7) + (v12 >> 7) + (v23 >> 7);        // byte i = col_ordered_i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = cur.w[i], n = i == 0 ? n0 : i == 1 ? n1 : i == 2 ? n2 : n3;
+        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8) & 0x00808080u;
+        const uint32_t c = popc(h) + ((colcnt >> (8 * i)) & 0xffu);
+        r += (double)c * 0.1;
+    }
+    return r;
+}
+
+// done <=> no direction changes the board (environment/game_2048.py:279-288): a full board
+// without equal neighbours, or (degenerate) an all-empty board. pair_count is defined below.
+G2048_HD uint32_t pair_count(const Board &b);
+G2048_HD bool game_over_counted(const Board &b, uint32_t n_empty)
+{
+    if (n_empty == 16u) return true;
+    if (n_empty != 0u) return false;
+    return pair_count(b) == 0u;
+}
+
+// Game2048Env.step (environment/game_2048.py:170-210) for one board: move (:185), valid (:188),
+// spawn iff valid (:191-192), reward on the post-spawn board (:195), done (:198), highest tile
+// (:201-203, always the current max inside step()). h is the board's 32-bit draw for this step.
+struct StepOut { Board board; uint32_t gain; double reward; uint32_t flags; };
+
+G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
+{
+    StepOut o;
+    Board cur = move_env(prev, action, o.gain);
+    const bool valid = !same(cur, prev);
+    const uint32_t empty_before = count_empty(prev);
+    {
+        Board spawned = cur;
+        spawn(spawned, h);
+        cur.w[0] = valid ? spawned.w[0] : cur.w[0]; cur.w[1] = valid ? spawned.w[1] : cur.w[1];
+        cur.w[2] = valid ? spawned.w[2] : cur.w[2]; cur.w[3] = valid ? spawned.w[3] : cur.w[3];
+    }
+    const uint32_t empty_after = count_empty(cur);
+    const TileStats st = tile_stats(cur);
+    o.reward = reward_env(cur, st, o.gain, valid, empty_before, empty_after);
+    const bool done = game_over_counted(cur, empty_after);
+    const uint32_t maxcode = 31u - (uint32_t)__builtin_clz(st.orbits | 1u);
+    o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);
+    o.board = cur;
+    return o;
+}
+
+// ------------------------------------------------------------- heuristics -----
+G2048_HD uint32_t pair_count(const Board &b)      // adjacent equal non-zero pairs, h + v
+{
+    uint32_t cnt = popc(eqnzflag(b.w[0], b.w[1])) + popc(eqnzflag(b.w[1], b.w[2])) + popc(eqnzflag(b.w[2], b.w[3]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cnt += popc(eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u);
+    return cnt;
+}
+
+G2048_HD uint32_t max_corner_code(const Board &b)
+{
+    const uint32_t a = b.w[0] & 0xffu, c = b.w[0] >> 24, d = b.w[3] & 0xffu, e = b.w[3] >> 24;
+    const uint32_t m0 = a > c ? a : c, m1 = d > e ? d : e;
+    return m0 > m1 ? m0 : m1;
+}
+
+// BeamSearchAgent._fast_evaluate (agents/beam_search_agent.py:280-314):
+// empty*10 + log2(max)*2 + max non-empty corner*2 + 2*(#adjacent equal pairs). Integer-valued.
+G2048_HD double eval_fast(const Board &b)
+{
+    const uint32_t e = count_empty(b);
+    const uint32_t mc = max_code(b);
+    const uint32_t cc = max_corner_code(b);
+    const uint32_t corner = cc ? (2u << cc) : 0u;
+    const double empty_score = (double)e * 10.0;
+    const double max_score = (double)mc * 2.0;
+    return ((empty_score + max_score) + (double)corner) + (double)(pair_count(b) * 2u);
+}
+
+// sum of codes over adjacent equal non-zero pairs (_calculate_merge_potential, :387-403)
+G2048_HD uint32_t merge_potential(const Board &b)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t f = eqnzflag(b.w[r], b.w[r + 1]);
+        acc = dot4(b.w[r], f >> 7, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t f = eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u;
+        acc = dot4(b.w[r], f >> 7, acc);
+    }
+    return acc;
+}
+
+// BeamSearchAgent._evaluate_state (agents/beam_search_agent.py:316-373), phase 0/1/2 =
+// early/mid/late (:271-278), f64, same operation order. snake_patterns[0] (:37-42).
+G2048_HD double eval_full(const Board &b, uint32_t phase)
+{
+    const double we = phase == 0 ? 15.0 : phase == 1 ? 10.0 : 8.0;
+    const double wm = phase == 0 ? 1.0 : phase == 1 ? 1.5 : 2.0;
+    const double wc = phase == 0 ? 2.0 : phase == 1 ? 2.5 : 3.0;
+    const double wg = phase == 0 ? 2.0 : phase == 1 ? 1.5 : 1.0;
+    const uint32_t e = count_empty(b);
+    double empty_score = (double)e * we;
+    if (e <= 2u) empty_score -= 10.0;
+    const uint32_t mc = max_code(b);
+    double max_score = (double)mc * wm;
+    if (mc >= 9u) max_score *= 1.2;
+    if (mc >= 10u) max_score *= 1.5;
+    if (mc >= 11u) max_score *= 2.0;
+    const double corner_bonus = ((double)max_corner_code(b) * 2.0) * wc;
+    const double mp = (double)merge_potential(b) * wg;
+    uint32_t sn = dot4(b.w[0], 0x0c0d0e0fu, 0u);      // 15 14 13 12
+    sn = dot4(b.w[1], 0x0b0a0908u, sn);               //  8  9 10 11
+    sn = dot4(b.w[2], 0x04050607u, sn);               //  7  6  5  4
+    sn = dot4(b.w[3], 0x03020100u, sn);               //  0  1  2  3
+    const double snake = (double)sn / 100.0;
+    return (((empty_score + max_score) + corner_bonus) + mp) + snake;
+}
+
+// agents/beam_search_agent.py:271-278 with thresholds as tile values
+G2048_HD uint32_t phase_of(uint32_t maxcode, uint32_t early_thr, uint32_t mid_thr)
+{
+    const uint32_t tile = maxcode ? (1u << maxcode) : 0u;
+    return tile < early_thr ? 0u : (tile < mid_thr ? 1u : 2u);
+}
+
+// PPOAgent.monotonicity counts (agents/ppo_agent.py:300-333): pairs with both > 0;
+// rle/rge over the 12 horizontal pairs (a <= b / a >= b), cle/cge over the 12 vertical ones.
+struct MonoCounts { uint32_t rle, rge, cle, cge; };
+
+G2048_HD MonoCounts mono_counts(const Board &b)
+{
+    MonoCounts m = {0, 0, 0, 0};
+    const uint32_t n0 = nzflag(b.w[0]), n1 = nzflag(b.w[1]), n2 = nzflag(b.w[2]), n3 = nzflag(b.w[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t x = b.w[r], n = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
+        const uint32_t both = n & (n >> 8) & 0x00808080u;
+        m.rle += popc(geflag(x >> 8, x) & both);
+        m.rge += popc(geflag(x, x >> 8) & both);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t na = r == 0 ? n0 : r == 1 ? n1 : n2, nb = r == 0 ? n1 : r == 1 ? n2 : n3;
+        m.cle += popc(geflag(b.w[r + 1], b.w[r]) & na & nb);
+        m.cge += popc(geflag(b.w[r], b.w[r + 1]) & na & nb);
+    }
+    return m;
+}
+
+// PPOAgent.evaluate_heuristic (agents/ppo_agent.py:271-298)
+G2048_HD double eval_ppo_heuristic(const Board &b)
+{
+    const MonoCounts m = mono_counts(b);
+    const uint32_t best = (m.rle > m.rge ? m.rle : m.rge) + (m.cle > m.cge ? m.cle : m.cge);
+    double score = 0.0;
+    score += 2.0 * ((double)best / 24.0);
+    if (max_corner_code(b) == max_code(b)) score += 1.0;
+    // tiles >= 8  <=>  code >= 3
+    const uint32_t c3 = 0x03030303u;
+    const uint32_t high = popc(geflag(b.w[0], c3)) + popc(geflag(b.w[1], c3)) + popc(geflag(b.w[2], c3)) + popc(geflag(b.w[3], c3));
+    if (high > 0u) score += -0.1 * (double)high;
+    return score;
+}
+
+G2048_HD double eval_monotonicity(const Board &b, int kind /*0 ++,1 +-,2 -+,3 --*/)
+{
+    const MonoCounts m = mono_counts(b);
+    const uint32_t r = (kind & 2) ? m.rge : m.rle;
+    const uint32_t c = (kind & 1) ? m.cge : m.cle;
+    return (double)(r + c) / 24.0;
+}
+
+}  // namespace g2048

@@ -1,0 +1,400 @@
+// g2048_kernels.hip -- batched env / heuristic kernels for gfx950 and their C-ABI (include/g2048.h).
+//
+// Mapping: one lane owns one board for the compute kernels (16-byte vector load/store per lane,
+// 1 KiB per wave-instruction, fully coalesced); the pure format kernels (obs / pack / unpack) give
+// one board ROW to a lane so that their wide side is a 16-byte access per lane as well.
+// No LDS, no MFMA: the work is integer SWAR on four VGPRs per board (g2048_board.h) plus ~20 f64
+// operations for the shaped reward. Compile with -ffp-contract=off (reward / eval operation order).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/g2048.h"
+#include "g2048_board.h"
+#include "g2048_rng.h"
+
+using namespace g2048;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G2048_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return G2048_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+constexpr int kBlock = 256;
+inline unsigned blocks_for(size_t n, int per_block = kBlock) { return (unsigned)((n + per_block - 1) / per_block); }
+
+__device__ __forceinline__ Board load_board(const uint4 *p, size_t i)
+{
+    const uint4 v = p[i];
+    return Board{{v.x, v.y, v.z, v.w}};
+}
+
+__device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
+{
+    p[i] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+}
+
+// ------------------------------------------------------------------ step ------
+// Game2048Env.step (environment/game_2048.py:170-210) for one board per lane.
+template <bool REWARD_F64, bool AUTO_RESET>
+__global__ __launch_bounds__(kBlock) void step_kernel(const uint4 *boards_in,       // may alias boards_out
+                                                     const uint8_t *__restrict__ actions,
+                                                     uint4 *boards_out,
+                                                     uint32_t *__restrict__ score,
+                                                     void *__restrict__ reward_out,
+                                                     uint8_t *__restrict__ flags_out,
+                                                     uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
+                                                     uint64_t id_base, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Board prev = load_board(boards_in, i);
+    const uint32_t action = actions[i] & 3u;
+    uint32_t sc = score[i];
+
+    const StepOut o = step_board(prev, action, rng_draw(k0, k1, id_base + i, 0u));
+    Board cur = o.board;
+    sc += o.gain;
+    const uint8_t fl = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
+    const bool done = (o.flags & G2048_FLAG_DONE) != 0u;
+    const double r = o.reward;
+    if (AUTO_RESET) {
+        if (done) {
+            cur = fresh_board(rng_draw(e0, e1, id_base + i, 0u), rng_draw(e0, e1, id_base + i, 1u));
+            sc = 0u;
+        }
+    }
+    store_board(boards_out, i, cur);
+    score[i] = sc;
+    if (REWARD_F64) static_cast<double *>(reward_out)[i] = r;
+    else static_cast<float *>(reward_out)[i] = (float)r;
+    flags_out[i] = fl;
+}
+
+// ------------------------------------------------------------------ reset -----
+__global__ __launch_bounds__(kBlock) void reset_kernel(uint4 *__restrict__ boards_out, uint32_t *__restrict__ score_out,
+                                                      uint32_t k0, uint32_t k1, uint64_t id_base, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    store_board(boards_out, i, fresh_board(rng_draw(k0, k1, id_base + i, 0u), rng_draw(k0, k1, id_base + i, 1u)));
+    if (score_out) score_out[i] = 0u;
+}
+
+// ------------------------------------------------------------ valid moves -----
+template <bool AGENT>
+__global__ __launch_bounds__(kBlock) void valid_kernel(const uint4 *__restrict__ boards, uint8_t *__restrict__ mask_out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Board b = load_board(boards, i);
+    mask_out[i] = (uint8_t)(AGENT ? valid_mask_agent(b, false) : valid_mask_env(b));
+}
+
+// ------------------------------------------------------------------- eval -----
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ phase,
+                                                     double *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Board b = load_board(boards, i);
+    double v;
+    if (KIND == G2048_EVAL_FAST) v = eval_fast(b);
+    else if (KIND == G2048_EVAL_FULL) v = eval_full(b, phase ? (uint32_t)phase[i] : phase_of(max_code(b), 512u, 1024u));
+    else if (KIND == G2048_EVAL_PPO_HEURISTIC) v = eval_ppo_heuristic(b);
+    else v = eval_monotonicity(b, KIND - G2048_EVAL_MONO_PP);
+    out[i] = v;
+}
+
+// -------------------------------------------------- format kernels (row/lane) -
+// PPOAgent.normalize_state (agents/ppo_agent.py:184-195): float32(code) / float32(15)
+__global__ __launch_bounds__(kBlock) void obs_kernel(const uint32_t *__restrict__ rows, float4 *__restrict__ obs, size_t n_rows)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t x = rows[i];
+    obs[i] = make_float4((float)(x & 0xffu) / 15.0f, (float)((x >> 8) & 0xffu) / 15.0f,
+                         (float)((x >> 16) & 0xffu) / 15.0f, (float)(x >> 24) / 15.0f);
+}
+
+__global__ __launch_bounds__(kBlock) void pack_kernel(const int4 *__restrict__ tiles, uint32_t *__restrict__ rows, size_t n_rows)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rows) return;
+    const int4 t = tiles[i];
+    auto code = [](int v) -> uint32_t { return v > 0 ? 31u - (uint32_t)__builtin_clz((uint32_t)v) : 0u; };
+    rows[i] = code(t.x) | (code(t.y) << 8) | (code(t.z) << 16) | (code(t.w) << 24);
+}
+
+__global__ __launch_bounds__(kBlock) void unpack_kernel(const uint32_t *__restrict__ rows, int4 *__restrict__ tiles, size_t n_rows)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t x = rows[i];
+    auto tile = [](uint32_t c) -> int { return c ? (int)(1u << c) : 0; };
+    tiles[i] = make_int4(tile(x & 0xffu), tile((x >> 8) & 0xffu), tile((x >> 16) & 0xffu), tile(x >> 24));
+}
+
+// ------------------------------------------------------------- synthetic ------
+__global__ __launch_bounds__(kBlock) void synth_boards_kernel(uint4 *__restrict__ boards, uint32_t k0, uint32_t k1,
+                                                             uint64_t id_base, size_t n, uint32_t p_empty, uint32_t max_code_)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Board b = {{0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (uint32_t cell = 0; cell < 16; ++cell) {
+        const uint32_t h = rng_draw(k0, k1, id_base + i, cell);
+        const uint32_t c = (h >> 16) < p_empty ? 0u : 1u + (((h & 0xffffu) * max_code_) >> 16);
+        b.w[cell >> 2] |= c << (8 * (cell & 3));
+    }
+    if ((b.w[0] | b.w[1] | b.w[2] | b.w[3]) == 0u) b.w[0] = 1u;
+    store_board(boards, i, b);
+}
+
+__global__ __launch_bounds__(kBlock) void synth_actions_kernel(uint8_t *__restrict__ actions, uint32_t k0, uint32_t k1,
+                                                              uint64_t id_base, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    actions[i] = (uint8_t)(rng_draw(k0, k1, id_base + i, 0u) >> 30);
+}
+
+// --------------------------------------------------------------- metrics ------
+__global__ __launch_bounds__(kBlock) void metrics_kernel(const uint4 *__restrict__ boards, const uint32_t *__restrict__ score,
+                                                        const uint8_t *__restrict__ flags, const uint32_t *__restrict__ expanded,
+                                                        unsigned long long *__restrict__ out, size_t n)
+{
+    __shared__ unsigned long long acc[24];
+    if (threadIdx.x < 24) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long cnt = 0, ssum = 0, dsum = 0, esum = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const Board b = load_board(boards, i);
+        cnt += 1ull;
+        ssum += score ? score[i] : 0u;
+        dsum += flags ? (flags[i] & G2048_FLAG_DONE) : 0u;
+        esum += expanded ? expanded[i] : 0u;
+        atomicAdd(&acc[4 + max_code(b)], 1ull);
+    }
+    // wave reduction of the four scalars, then one LDS atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off); ssum += __shfl_down(ssum, off);
+        dsum += __shfl_down(dsum, off); esum += __shfl_down(esum, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], cnt); atomicAdd(&acc[1], ssum); atomicAdd(&acc[2], dsum); atomicAdd(&acc[3], esum);
+    }
+    __syncthreads();
+    if (threadIdx.x < 22 && acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
+}
+
+// -------------------------------------------------------------- self-test -----
+__global__ void selftest_kernel(uint32_t *result, uint32_t a, uint32_t b, double x, double y, double z)
+{
+    uint32_t bad = 0;
+    // v_perm_b32: selector 0..3 -> bytes of the SECOND operand, 4..7 -> bytes of the FIRST, 0x0c -> 0
+    if (perm(a, b, 0x07040300u) != (((a >> 24) << 24) | ((a & 0xffu) << 16) | ((b >> 24) << 8) | (b & 0xffu))) bad |= 1u;
+    if (perm(a, b, 0x0c0c0c05u) != ((a >> 8) & 0xffu)) bad |= 2u;
+    if (dot4(a, b, 7u) != 7u + (a & 0xffu) * (b & 0xffu) + ((a >> 8) & 0xffu) * ((b >> 8) & 0xffu) +
+                              ((a >> 16) & 0xffu) * ((b >> 16) & 0xffu) + (a >> 24) * (b >> 24)) bad |= 4u;
+    // contraction must be off: x*y is rounded before the add
+    if (x * y + z != 0.0) bad |= 8u;
+    // transpose / rot180 of a counting board
+    const Board c = {{0x03020100u, 0x07060504u, 0x0b0a0908u, 0x0f0e0d0cu}};
+    const Board t = transpose(c);
+    if (t.w[0] != 0x0c080400u || t.w[1] != 0x0d090501u || t.w[2] != 0x0e0a0602u || t.w[3] != 0x0f0b0703u) bad |= 16u;
+    const Board r = rot180(c);
+    if (r.w[0] != 0x0c0d0e0fu || r.w[3] != 0x00010203u) bad |= 32u;
+    *result = bad;
+}
+
+}  // namespace
+
+// ==================================================================== C-ABI ====
+extern "C" {
+
+const char *g2048_last_error(void) { return g_err; }
+// internal: lets the other translation units of this library report through the same string
+void g2048_set_last_error_(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+int g2048_abi_version(void) { return G2048_ABI_VERSION; }
+
+int g2048_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+               void *reward_out, uint8_t *flags_out, uint64_t seed, uint64_t step_index,
+               uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards_in || !actions || !boards_out || !score_inout || !reward_out || !flags_out)
+        return fail(G2048_ERR_ARG, "g2048_step: null pointer");
+    if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
+    if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
+        return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET)) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(blocks_for(n)), block(kBlock);
+    const uint4 *in = static_cast<const uint4 *>(boards_in);
+    uint4 *out = static_cast<uint4 *>(boards_out);
+    const bool f64 = opts & G2048_STEP_REWARD_F64, ar = opts & G2048_STEP_AUTO_RESET;
+#define G2048_LAUNCH_STEP(F, A) \
+    hipLaunchKernelGGL((step_kernel<F, A>), grid, block, 0, s, in, actions, out, score_inout, reward_out, flags_out, \
+                       k.k0, k.k1, e.k0, e.k1, board_id_base, n)
+    if (f64 && ar) G2048_LAUNCH_STEP(true, true);
+    else if (f64) G2048_LAUNCH_STEP(true, false);
+    else if (ar) G2048_LAUNCH_STEP(false, true);
+    else G2048_LAUNCH_STEP(false, false);
+#undef G2048_LAUNCH_STEP
+    return check_launch("g2048_step");
+}
+
+int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch, uint64_t board_id_base,
+                size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards_out) return fail(G2048_ERR_ARG, "g2048_reset: null pointer");
+    if (!aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_reset: board array must be 16-byte aligned");
+    const Keys k = rng_keys(seed, DOM_RESET, epoch);
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint4 *>(boards_out), score_out, k.k0, k.k1, board_id_base, n);
+    return check_launch("g2048_reset");
+}
+
+int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t opts, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !mask4_out) return fail(G2048_ERR_ARG, "g2048_valid_moves: null pointer");
+    if (!aligned16(boards)) return fail(G2048_ERR_ARG, "g2048_valid_moves: board array must be 16-byte aligned");
+    if (opts > G2048_VALID_AGENT) return fail(G2048_ERR_ARG, "g2048_valid_moves: unknown opts 0x%x", opts);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint4 *b = static_cast<const uint4 *>(boards);
+    if (opts == G2048_VALID_AGENT) hipLaunchKernelGGL(valid_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
+    else hipLaunchKernelGGL(valid_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
+    return check_launch("g2048_valid_moves");
+}
+
+int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !out) return fail(G2048_ERR_ARG, "g2048_eval: null pointer");
+    if (!aligned16(boards) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(G2048_ERR_ARG, "g2048_eval: misaligned array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint4 *b = static_cast<const uint4 *>(boards);
+    const dim3 grid(blocks_for(n)), block(kBlock);
+    switch (kind) {
+#define G2048_EVAL_CASE(K) case K: hipLaunchKernelGGL(eval_kernel<K>, grid, block, 0, s, b, phase_or_null, out, n); break;
+        G2048_EVAL_CASE(G2048_EVAL_FAST)
+        G2048_EVAL_CASE(G2048_EVAL_FULL)
+        G2048_EVAL_CASE(G2048_EVAL_PPO_HEURISTIC)
+        G2048_EVAL_CASE(G2048_EVAL_MONO_PP)
+        G2048_EVAL_CASE(G2048_EVAL_MONO_PM)
+        G2048_EVAL_CASE(G2048_EVAL_MONO_MP)
+        G2048_EVAL_CASE(G2048_EVAL_MONO_MM)
+#undef G2048_EVAL_CASE
+        default: return fail(G2048_ERR_ARG, "g2048_eval: unknown kind %d", kind);
+    }
+    return check_launch("g2048_eval");
+}
+
+int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !obs_out) return fail(G2048_ERR_ARG, "g2048_obs_f32: null pointer");
+    if (!aligned16(boards) || !aligned16(obs_out)) return fail(G2048_ERR_ARG, "g2048_obs_f32: arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(obs_kernel, dim3(blocks_for(n * 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint32_t *>(boards), reinterpret_cast<float4 *>(obs_out), n * 4);
+    return check_launch("g2048_obs_f32");
+}
+
+int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!tiles || !boards_out) return fail(G2048_ERR_ARG, "g2048_pack_i32: null pointer");
+    if (!aligned16(tiles) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_pack_i32: arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n * 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const int4 *>(tiles), static_cast<uint32_t *>(boards_out), n * 4);
+    return check_launch("g2048_pack_i32");
+}
+
+int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !tiles_out) return fail(G2048_ERR_ARG, "g2048_unpack_i32: null pointer");
+    if (!aligned16(boards) || !aligned16(tiles_out)) return fail(G2048_ERR_ARG, "g2048_unpack_i32: arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(n * 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint32_t *>(boards), reinterpret_cast<int4 *>(tiles_out), n * 4);
+    return check_launch("g2048_unpack_i32");
+}
+
+int g2048_synth_boards(void *boards_out, uint64_t seed, uint64_t board_id_base, size_t n, uint32_t p_empty_u16,
+                       uint32_t max_code_, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards_out) return fail(G2048_ERR_ARG, "g2048_synth_boards: null pointer");
+    if (!aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_synth_boards: board array must be 16-byte aligned");
+    if (max_code_ < 1 || max_code_ > 17 || p_empty_u16 > 65536) return fail(G2048_ERR_ARG, "g2048_synth_boards: bad distribution");
+    const Keys k = rng_keys(seed, DOM_SYNTH_BOARD, 0);
+    hipLaunchKernelGGL(synth_boards_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint4 *>(boards_out), k.k0, k.k1, board_id_base, n, p_empty_u16, max_code_);
+    return check_launch("g2048_synth_boards");
+}
+
+int g2048_synth_actions(uint8_t *actions_out, uint64_t seed, uint64_t step_index, uint64_t board_id_base, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!actions_out) return fail(G2048_ERR_ARG, "g2048_synth_actions: null pointer");
+    const Keys k = rng_keys(seed, DOM_SYNTH_ACTION, step_index);
+    hipLaunchKernelGGL(synth_actions_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       actions_out, k.k0, k.k1, board_id_base, n);
+    return check_launch("g2048_synth_actions");
+}
+
+int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flags_or_null, const uint32_t *expanded_or_null,
+                  unsigned long long *out24, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !out24) return fail(G2048_ERR_ARG, "g2048_metrics: null pointer");
+    if (!aligned16(boards)) return fail(G2048_ERR_ARG, "g2048_metrics: board array must be 16-byte aligned");
+    unsigned grid = blocks_for(n);
+    if (grid > 2048u) grid = 2048u;
+    hipLaunchKernelGGL(metrics_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(boards), score, flags_or_null, expanded_or_null, out24, n);
+    return check_launch("g2048_metrics");
+}
+
+int g2048_selftest(uint32_t *result_out, void *stream)
+{
+    if (!result_out) return fail(G2048_ERR_ARG, "g2048_selftest: null pointer");
+    volatile double x = 0.1, y = 3.0;
+    const double p = x * y;        // rounded product, computed on the host
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), result_out,
+                       0xA3A2A1A0u, 0xB3B2B1B0u, (double)x, (double)y, -p);
+    return check_launch("g2048_selftest");
+}
+
+}  // extern "C"

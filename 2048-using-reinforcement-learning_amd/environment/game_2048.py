@@ -1,0 +1,112 @@
+"""Drop-in for the reference's environment/game_2048.py: same class name, methods, return types.
+
+One board living on the GPU and stepped by the same HIP kernel that steps millions
+(`g2048_step` with n = 1). It exists so that scripts written against the reference
+(`train.py`-shaped loops, `agents/ppo_agent.py`) run unchanged; for throughput use
+`g2048.VecGame2048`. Differences from the reference, all deliberate:
+  * tile spawns come from the engine's counter RNG, not from Python's global `random`
+    (the seed defaults to one draw from `random`, so `random.seed(k)` still pins a run);
+  * size != 4 raises (the reference's agents hard-code 4x4: beam_search_agent.py:69,378).
+"""
+import random
+
+import numpy as np
+import torch
+
+from g2048 import _lib as L
+from g2048 import ops
+
+
+class Game2048Env:
+    ACTIONS = {0: "LEFT", 1: "UP", 2: "RIGHT", 3: "DOWN"}      # reference :11-16
+
+    def __init__(self, size=4, seed=None, device="cuda"):
+        if size != 4:
+            raise ValueError("Game2048Env: only size=4 is supported by the MI355X engine")
+        self.size = size
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Game2048Env: needs a ROCm device; there is no CPU path")
+        L.lib()
+        self.seed = random.getrandbits(63) if seed is None else int(seed)
+        self._boards = torch.zeros((1, 16), dtype=torch.uint8, device=self.device)
+        self._scores = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._action = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        self._reward = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._flags = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        self._t = 0
+        self._epoch = 0
+        self.highest_tile = 0
+        self.reset()
+
+    # -- state mirrors (host copies refreshed after every device call) -------
+    @property
+    def board(self):
+        return self._board_np
+
+    @board.setter
+    def board(self, value):
+        tiles = torch.as_tensor(np.ascontiguousarray(value, dtype=np.int32).reshape(1, 16), device=self.device)
+        ops.pack(tiles, out=self._boards)
+        self._board_np = np.array(value, dtype=np.int32).reshape(4, 4).copy()
+
+    @property
+    def score(self):
+        return self._score
+
+    @score.setter
+    def score(self, value):
+        self._score = value
+        self._scores.fill_(int(value))
+
+    def _pull(self):
+        self._board_np = ops.unpack(self._boards).cpu().numpy().reshape(4, 4)
+        self._score = np.int32(self._scores.item())
+
+    # -- reference API ---------------------------------------------------------
+    def reset(self):                                           # reference :29-48
+        ops.reset(1, self.seed, self._epoch, 0, boards=self._boards, scores=self._scores)
+        self._epoch += 1
+        self._pull()
+        self._score = 0
+        self.game_over = False
+        self.highest_tile = np.max(self._board_np)
+        return self.get_state()
+
+    def get_state(self):                                       # reference :50-57
+        return self._board_np.flatten()
+
+    def get_valid_moves(self):                                 # reference :69-95
+        m = int(ops.valid_moves(self._boards).item())
+        return [bool((m >> a) & 1) for a in range(4)]
+
+    def step(self, action):                                    # reference :170-210
+        self._action.fill_(int(action) & 3)
+        ops.step(self._boards, self._action, self._scores, self.seed, self._t, 0, out=self._boards,
+                 reward=self._reward, flags=self._flags, reward_f64=True)
+        self._t += 1
+        flags = int(self._flags.item())
+        self._pull()
+        reward = np.float64(self._reward.item())
+        self.game_over = bool(flags & L.FLAG_DONE)
+        current_highest = np.max(self._board_np)
+        if current_highest > self.highest_tile:
+            self.highest_tile = current_highest
+        return self.get_state(), reward, self.game_over, {
+            "score": self._score,
+            "valid_move": bool(flags & L.FLAG_VALID),
+            "highest_tile": self.highest_tile,
+        }
+
+    def is_game_over(self):                                    # reference :279-288
+        return not any(self.get_valid_moves())
+
+    def render(self, mode="human"):                            # reference :290-311 (host-side text)
+        if mode == "human":
+            print("-" * (5 * self.size + 1))
+            for row in self._board_np:
+                print("|" + "".join("    |" if int(t) == 0 else "%4d|" % int(t) for t in row))
+                print("-" * (5 * self.size + 1))
+            print("Score: %s" % self._score)
+            print("Highest Tile: %s" % self.highest_tile)
+            print()

@@ -1,0 +1,42 @@
+"""Builds csrc/libg2048_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m g2048._build            (from the package directory)
+
+The library is built in-tree so that it travels with the source snapshot; it is
+git-ignored. -ffp-contract=off is REQUIRED: the reward / heuristic kernels follow
+the reference's f64 operation order (mul then add, never fma).
+"""
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+LIB = os.path.join(CSRC, "libg2048_hip.so")
+SOURCES = ["g2048_kernels.hip", "g2048_beam.hip"]
+HEADERS = ["g2048_board.h", "g2048_rng.h", os.path.join("..", "..", "include", "g2048.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI in include/g2048.h (csrc/libg2048_hip.so).
+
+There is no fallback: if the library is missing or no HIP device is visible, every
+compute call raises. PyTorch is only used for device memory and streams -- tensors
+are passed as data_ptr(), work is enqueued on torch's current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _build
+
+_lib = None
+
+OK = 0
+FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
+STEP_REWARD_F64, STEP_AUTO_RESET = 0x01, 0x02
+VALID_ENV, VALID_AGENT = 0, 1
+EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM = range(7)
+BEAM_FIXED_DOWN = 0x01
+BEAM_MAX_WIDTH = 32
+
+_vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
+SIGNATURES = {
+    "g2048_last_error": (C.c_char_p, []),
+    "g2048_abi_version": (_int, []),
+    "g2048_device_count": (_int, []),
+    "g2048_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _u32, _vp]),
+    "g2048_reset": (_int, [_vp, _vp, _u64, _u64, _u64, _sz, _vp]),
+    "g2048_valid_moves": (_int, [_vp, _vp, _sz, _u32, _vp]),
+    "g2048_eval": (_int, [_vp, _int, _vp, _vp, _sz, _vp]),
+    "g2048_obs_f32": (_int, [_vp, _vp, _sz, _vp]),
+    "g2048_beam_get_action": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _u64, _u64, _u64, _sz, _u32, _vp]),
+    "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
+    "g2048_unpack_i32": (_int, [_vp, _vp, _sz, _vp]),
+    "g2048_synth_boards": (_int, [_vp, _u64, _u64, _sz, _u32, _u32, _vp]),
+    "g2048_synth_actions": (_int, [_vp, _u64, _u64, _u64, _sz, _vp]),
+    "g2048_metrics": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2048_selftest": (_int, [_vp, _vp]),
+}
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """The loaded C-ABI library. Raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError("g2048: %s is missing -- build it with `python __graft_entry__.py` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        L = C.CDLL(path)        # torch is imported above, so libamdhip64 resolves to the runtime torch uses
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError here = ABI mismatch, deliberately loud
+            fn.restype, fn.argtypes = res, args
+        if L.g2048_abi_version() != 1:
+            raise RuntimeError("g2048: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise RuntimeError("g2048: %s (status %d)" % (lib().g2048_last_error().decode(), rc))
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device_tensor(t, dtype, shape_tail=None, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("g2048: %s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("g2048: %s must live on a ROCm device (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("g2048: %s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("g2048: %s must be contiguous" % name)
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError("g2048: %s must have shape (n,%s) (got %s)" % (name, ",".join(map(str, shape_tail)), tuple(t.shape)))
+    return t
+
+
+def u64(x):
+    return int(x) & 0xFFFFFFFFFFFFFFFF

@@ -1,0 +1,173 @@
+"""Tensor-in / tensor-out wrappers of the C-ABI (one function per entry point of include/g2048.h).
+
+Boards are torch.uint8 tensors of shape (n, 16) holding log2 codes (0 = empty), on a ROCm device.
+Every call is enqueued on torch's current stream of the boards' device and returns immediately.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _dev(t):
+    return t.device
+
+
+def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=None, flags=None,
+         reward_f64=False, auto_reset=False):
+    """Game2048Env.step for every board (reference environment/game_2048.py:170-210).
+
+    scores (uint32) is updated in place. Returns (boards_out, reward, flags); flags bit0 = done,
+    bit1 = valid move, bits 3..7 = max log2 code. `out` may be `boards` for an in-place step."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    n = boards.shape[0]
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    L.require_device_tensor(scores, torch.int32 if scores.dtype == torch.int32 else torch.uint32, None, "scores")
+    if actions.shape[0] != n or scores.shape[0] != n:
+        raise ValueError("g2048: actions/scores length must equal the number of boards")
+    dev = _dev(boards)
+    if out is None:
+        out = torch.empty_like(boards)
+    rdt = torch.float64 if reward_f64 else torch.float32
+    if reward is None:
+        reward = torch.empty(n, dtype=rdt, device=dev)
+    if flags is None:
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
+    L.require_device_tensor(out, torch.uint8, (16,), "out")
+    L.require_device_tensor(reward, rdt, None, "reward")
+    L.require_device_tensor(flags, torch.uint8, None, "flags")
+    opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0)
+    L.check(L.lib().g2048_step(boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+                               reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base),
+                               n, opts, L.stream_ptr(dev)))
+    return out, reward, flags
+
+
+def reset(n, seed, epoch=0, id_base=0, device="cuda", boards=None, scores=None):
+    """Game2048Env.reset for n boards (environment/game_2048.py:29-48). Returns (boards, scores)."""
+    dev = torch.device(device) if boards is None else boards.device
+    if boards is None:
+        boards = torch.empty((n, 16), dtype=torch.uint8, device=dev)
+    if scores is None:
+        scores = torch.empty(n, dtype=torch.int32, device=dev)
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    L.require_device_tensor(scores, scores.dtype if scores.dtype in (torch.int32, torch.uint32) else torch.int32, None, "scores")
+    L.check(L.lib().g2048_reset(boards.data_ptr(), scores.data_ptr(), L.u64(seed), L.u64(epoch), L.u64(id_base),
+                                boards.shape[0], L.stream_ptr(dev)))
+    return boards, scores
+
+
+def valid_moves(boards, agent_semantics=False, out=None):
+    """4-bit masks (bit a = action a valid). Env semantics (game_2048.py:69-95) or the beam agent's own
+    (_check_valid_moves, beam_search_agent.py:183-192 -- differs on DOWN)."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if out is None:
+        out = torch.empty(boards.shape[0], dtype=torch.uint8, device=boards.device)
+    L.require_device_tensor(out, torch.uint8, None, "out")
+    L.check(L.lib().g2048_valid_moves(boards.data_ptr(), out.data_ptr(), boards.shape[0],
+                                      L.VALID_AGENT if agent_semantics else L.VALID_ENV, L.stream_ptr(boards.device)))
+    return out
+
+
+def evaluate(boards, kind, phase=None, out=None):
+    """Board heuristics in f64: L.EVAL_FAST / EVAL_FULL (phase uint8 per board or None) /
+    EVAL_PPO_HEURISTIC / EVAL_MONO_*."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if phase is not None:
+        L.require_device_tensor(phase, torch.uint8, None, "phase")
+        if phase.shape[0] != boards.shape[0]:
+            raise ValueError("g2048: phase length must equal the number of boards")
+    if out is None:
+        out = torch.empty(boards.shape[0], dtype=torch.float64, device=boards.device)
+    L.require_device_tensor(out, torch.float64, None, "out")
+    L.check(L.lib().g2048_eval(boards.data_ptr(), int(kind), phase.data_ptr() if phase is not None else None,
+                               out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    return out
+
+
+def obs(boards, out=None):
+    """PPOAgent.normalize_state for every board (agents/ppo_agent.py:184-195): float32 (n,16)."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if out is None:
+        out = torch.empty((boards.shape[0], 16), dtype=torch.float32, device=boards.device)
+    L.require_device_tensor(out, torch.float32, (16,), "out")
+    L.check(L.lib().g2048_obs_f32(boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    return out
+
+
+def pack(tiles, out=None):
+    """int32 (n,16) real tile values (the reference's state layout) -> packed codes."""
+    L.require_device_tensor(tiles, torch.int32, (16,), "tiles")
+    if out is None:
+        out = torch.empty((tiles.shape[0], 16), dtype=torch.uint8, device=tiles.device)
+    L.check(L.lib().g2048_pack_i32(tiles.data_ptr(), out.data_ptr(), tiles.shape[0], L.stream_ptr(tiles.device)))
+    return out
+
+
+def unpack(boards, out=None):
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if out is None:
+        out = torch.empty((boards.shape[0], 16), dtype=torch.int32, device=boards.device)
+    L.check(L.lib().g2048_unpack_i32(boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    return out
+
+
+def synth_boards(n, seed=0x2048, id_base=0, p_empty=0.30, max_code=11, device="cuda", out=None):
+    """Synthetic boards of the benchmark configs, generated on the device."""
+    if out is None:
+        out = torch.empty((n, 16), dtype=torch.uint8, device=device)
+    L.require_device_tensor(out, torch.uint8, (16,), "out")
+    L.check(L.lib().g2048_synth_boards(out.data_ptr(), L.u64(seed), L.u64(id_base), out.shape[0],
+                                       int(round(p_empty * 65536)), int(max_code), L.stream_ptr(out.device)))
+    return out
+
+
+def synth_actions(n, seed=0x2048, step_index=0, id_base=0, device="cuda", out=None):
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=device)
+    L.require_device_tensor(out, torch.uint8, None, "out")
+    L.check(L.lib().g2048_synth_actions(out.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), out.shape[0],
+                                        L.stream_ptr(out.device)))
+    return out
+
+
+def metrics(boards, scores=None, flags=None, expanded=None, out=None):
+    """Per-shard metric vector (int64[24]): n, sum(score), #done, sum(expanded), hist of max code 0..17."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if out is None:
+        out = torch.zeros(24, dtype=torch.int64, device=boards.device)
+    L.check(L.lib().g2048_metrics(boards.data_ptr(), scores.data_ptr() if scores is not None else None,
+                                  flags.data_ptr() if flags is not None else None,
+                                  expanded.data_ptr() if expanded is not None else None,
+                                  out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    return out
+
+
+def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
+                    seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False):
+    """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
+    Returns (actions uint8, probs float32[, expanded int32])."""
+    L.require_device_tensor(roots, torch.uint8, (16,), "roots")
+    n = roots.shape[0]
+    if not (1 <= int(width) <= L.BEAM_MAX_WIDTH):
+        raise ValueError("g2048: beam width must be in 1..%d" % L.BEAM_MAX_WIDTH)
+    if valid_mask is not None:
+        L.require_device_tensor(valid_mask, torch.uint8, None, "valid_mask")
+        if valid_mask.shape[0] != n:
+            raise ValueError("g2048: valid_mask length must equal the number of roots")
+    dev = roots.device
+    actions = torch.empty(n, dtype=torch.uint8, device=dev)
+    probs = torch.empty(n, dtype=torch.float32, device=dev)
+    expanded = torch.empty(n, dtype=torch.int32, device=dev) if want_expanded else None
+    L.check(L.lib().g2048_beam_get_action(roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None,
+                                          actions.data_ptr(), probs.data_ptr(),
+                                          expanded.data_ptr() if expanded is not None else None,
+                                          int(width), int(depth), int(early_threshold), int(mid_threshold),
+                                          L.u64(seed), L.u64(step_index), L.u64(game_id_base), n,
+                                          L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev)))
+    return (actions, probs, expanded) if want_expanded else (actions, probs)
+
+
+def selftest(device="cuda"):
+    r = torch.full((1,), 0xFFFF, dtype=torch.int32, device=device)
+    L.check(L.lib().g2048_selftest(r.data_ptr(), L.stream_ptr(r.device)))
+    return int(r.item())

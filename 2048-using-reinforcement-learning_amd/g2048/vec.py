@@ -1,0 +1,107 @@
+"""Batched front-ends: thousands to millions of independent games resident on one GPU."""
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class VecGame2048:
+    """n independent Game2048Env instances living in HBM (reference environment/game_2048.py:4-210).
+
+    State: boards uint8 (n,16) log2 codes, scores int32 (n,). All draws are keyed by
+    (seed, global board id = id_base + i, step counter), so a run is reproducible and independent of
+    how boards are sharded over GPUs (one VecGame2048 per rank with its own id_base).
+    """
+
+    ACTIONS = {0: "LEFT", 1: "UP", 2: "RIGHT", 3: "DOWN"}      # game_2048.py:11-16
+
+    def __init__(self, n, device="cuda", seed=0x2048, id_base=0, auto_reset=False, reward_f64=False):
+        self.n = int(n)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("g2048: VecGame2048 needs a ROCm device (got %s); there is no CPU path" % self.device)
+        L.lib()
+        self.seed, self.id_base = int(seed), int(id_base)
+        self.auto_reset, self.reward_f64 = bool(auto_reset), bool(reward_f64)
+        self.boards = torch.zeros((self.n, 16), dtype=torch.uint8, device=self.device)
+        self._spare = torch.empty_like(self.boards)
+        self.scores = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        self.reward = torch.empty(self.n, dtype=torch.float64 if reward_f64 else torch.float32, device=self.device)
+        self.flags = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        self.t = 0            # step counter (RNG index)
+        self.epoch = 0        # reset counter (RNG index)
+        self.reset()
+
+    def reset(self):
+        """All boards: empty + two spawns, score 0. Returns the boards tensor (codes)."""
+        ops.reset(self.n, self.seed, self.epoch, self.id_base, boards=self.boards, scores=self.scores)
+        self.epoch += 1
+        self.flags.zero_()
+        return self.boards
+
+    def load(self, boards, scores=None):
+        """Overwrite the state (e.g. synthetic benchmark boards)."""
+        L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+        self.boards.copy_(boards)
+        if scores is None:
+            self.scores.zero_()
+        else:
+            self.scores.copy_(scores)
+        return self.boards
+
+    def step(self, actions):
+        """actions uint8 (n,). Returns (boards, reward, done(bool), info) -- tensors, no host sync.
+        info: score, valid_move, highest_tile (as in game_2048.py:206-210)."""
+        ops.step(self.boards, actions, self.scores, self.seed, self.t, self.id_base, out=self._spare,
+                 reward=self.reward, flags=self.flags, reward_f64=self.reward_f64, auto_reset=self.auto_reset)
+        self.boards, self._spare = self._spare, self.boards
+        self.t += 1
+        done = (self.flags & L.FLAG_DONE).bool()
+        info = {
+            "score": self.scores,
+            "valid_move": (self.flags & L.FLAG_VALID).bool(),
+            "highest_tile": torch.where(self.flags >> L.FLAG_MAXCODE_SHIFT > 0,
+                                        torch.ones((), dtype=torch.int32, device=self.device) << (self.flags >> L.FLAG_MAXCODE_SHIFT).int(),
+                                        torch.zeros((), dtype=torch.int32, device=self.device)),
+        }
+        return self.boards, self.reward, done, info
+
+    def valid_moves(self, agent_semantics=False):
+        """uint8 (n,) 4-bit masks, bit a = action a valid."""
+        return ops.valid_moves(self.boards, agent_semantics)
+
+    def valid_moves_bool(self):
+        m = self.valid_moves()
+        return torch.stack([(m >> a) & 1 for a in range(4)], dim=1).bool()
+
+    def obs(self):
+        """float32 (n,16): log2(tile)/15 (PPOAgent.normalize_state)."""
+        return ops.obs(self.boards)
+
+    def state_i32(self):
+        """int32 (n,16) real tile values -- the reference's get_state() layout."""
+        return ops.unpack(self.boards)
+
+    def random_actions(self):
+        return ops.synth_actions(self.n, self.seed, self.t, self.id_base, device=self.device)
+
+
+class BatchedBeamSearch:
+    """BeamSearchAgent.get_action for many games at once (reference agents/beam_search_agent.py:71-181)."""
+
+    def __init__(self, beam_width=10, search_depth=15, seed=0x2048, early_game_threshold=512,
+                 mid_game_threshold=1024, fixed_down=False):
+        if not (1 <= int(beam_width) <= L.BEAM_MAX_WIDTH):
+            raise ValueError("g2048: beam width must be in 1..%d" % L.BEAM_MAX_WIDTH)
+        self.beam_width, self.search_depth = int(beam_width), int(search_depth)
+        self.early_game_threshold, self.mid_game_threshold = int(early_game_threshold), int(mid_game_threshold)
+        self.seed, self.fixed_down = int(seed), bool(fixed_down)
+        self.decisions = 0
+
+    def get_actions(self, boards, valid_mask=None, game_id_base=0, want_expanded=False):
+        """boards uint8 (n,16). Returns (actions uint8, probs float32[, expanded])."""
+        res = ops.beam_get_action(boards, self.beam_width, self.search_depth, valid_mask, self.early_game_threshold,
+                                  self.mid_game_threshold, self.seed, self.decisions, game_id_base, self.fixed_down,
+                                  want_expanded)
+        self.decisions += 1
+        return res

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's benchmark (contract: python bench.py --gpus N --steps K --warmup W).
+
+A "step" is one pass of Game2048Env.step (g2048_step, HIP) over this rank's batch of synthetic boards:
+BASELINE.json configs[1] -- 1,048,576 boards per GPU (cells empty with p = 0.30, else codes uniform
+1..11; uniform actions, all four in every launch), inputs resident in HBM, reading a fixed input buffer
+and writing a separate output buffer so every step does identical work. With N GPUs every rank steps its
+own contiguous shard of 1,048,576 boards (global ids rank*1,048,576 ..., weak scaling, config 5); the only
+collective is the final all-gather of per-board scores over RCCL, issued after the timed region.
+
+Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs, max over ranks.
+The K launches are replayed from one hipGraph (launch-bound otherwise: a step is ~10-20 us of GPU time);
+pass --no-graph for eager launches. The roofline leg times the same kernel launch by launch with HIP
+events on the launch stream; the cpu_baseline leg times the CPU oracle (the C port of the reference
+algorithm, OpenMP over boards) on a bounded sample of the same workload, rank 0 at N = 1 only.
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import __graft_entry__ as ge  # noqa: E402
+
+BOARDS_PER_GPU = 1 << 20
+SEED = 0x2048
+STEP_BYTES_F32 = 46          # R board 16 + action 1 + score 4; W board 16 + score 4 + reward 4 + flags 1
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH = 4096, 20, 30
+BEAM_BYTES = 29              # SURVEY 8(d) HBM-resident-beam accounting per expansion
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-beam", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ge.import_package()
+    from g2048 import ops, _lib
+    _lib.lib()
+    assert ops.selftest(dev) == 0, "device self-test failed"
+
+    n = BOARDS_PER_GPU
+    id_base = rank * n
+    boards = ops.synth_boards(n, seed=SEED, id_base=id_base, device=dev)
+    actions = ops.synth_actions(n, seed=SEED, step_index=0, id_base=id_base, device=dev)
+    out = torch.empty_like(boards)
+    scores = torch.zeros(n, dtype=torch.int32, device=dev)
+    reward = torch.empty(n, dtype=torch.float32, device=dev)
+    flags = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def one_step(t):
+        ops.step(boards, actions, scores, SEED, t, id_base, out=out, reward=reward, flags=flags)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    K, W = args.steps, args.warmup
+    for t in range(W):
+        one_step(t)
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for t in range(K):
+                    one_step(W + t)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps -------------------------------------------------
+    scores.zero_()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for t in range(K):
+            one_step(W + t)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- final metrics reduction: all-gather of per-board scores (config 5), timed separately
+    gather_ms = None
+    if world > 1:
+        gathered = torch.empty(world * n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, scores)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert bool((gathered[rank * n:(rank + 1) * n] == scores).all())
+        m = ops.metrics(out, scores, flags)
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        assert int(m[0].item()) == world * n
+
+    # ---- roofline leg: the step kernel, launch by launch, HIP events on the launch stream ---
+    reps = min(max(K, 50), 400)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for t in range(reps):
+        evs[t][0].record()
+        one_step(W + t)
+        evs[t][1].record()
+    torch.cuda.synchronize()
+    durs = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3          # seconds
+    kernel_s = float(np.mean(durs))
+    achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
+
+    result = {
+        "metric": "board-steps/sec (batched env.step)",
+        "value": world * n * K / elapsed,
+        "unit": "board-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8 (packed log2 tiles; f64 reward arithmetic, f32 reward out)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batched env.step, 1,048,576 random boards per GPU "
+                               "(p_empty=0.30, codes 1..11), 4 actions per launch, input->output buffers",
+                   "boards_per_gpu": n, "launch": "hipGraph of K launches" if graph is not None else "eager",
+                   "parallelism": "%d shard(s) of 1,048,576 boards, no data-path collective" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "step_kernel<false,false>", "kernel_us": kernel_s * 1e6,
+                     "kernel_us_min": float(durs.min()) * 1e6,
+                     "algorithmic_bytes_per_launch": n * STEP_BYTES_F32},
+    }
+    if gather_ms is not None:
+        result["allgather_scores_ms"] = gather_ms
+
+    # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
+    if not args.no_beam:
+        roots = torch.cat([ops.synth_boards(BEAM_GAMES // 2, seed=SEED + 1, id_base=rank * BEAM_GAMES, device=dev),
+                           ops.synth_boards(BEAM_GAMES // 2, seed=SEED + 2, id_base=rank * BEAM_GAMES, p_empty=0.45,
+                                            max_code=9, device=dev)])
+        for w in range(2):
+            a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=w,
+                                          game_id_base=rank * BEAM_GAMES, want_expanded=True)
+        torch.cuda.synchronize()
+        breps = 10
+        bev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(breps)]
+        total_exp = 0
+        for w in range(breps):
+            bev[w][0].record()
+            a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w,
+                                          game_id_base=rank * BEAM_GAMES, want_expanded=True)
+            bev[w][1].record()
+            total_exp += int(e.sum().item())
+        torch.cuda.synchronize()
+        bsec = sum(x.elapsed_time(y) for x, y in bev) * 1e-3
+        result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games)",
+                          "value": total_exp / bsec, "unit": "expansions/s",
+                          "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
+                          "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
+                          "hbm_equivalent_GBs_at_29B": total_exp / bsec * BEAM_BYTES / 1e9}
+
+    # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+        from oracle import oracle as O
+        hb, ha = boards.cpu().numpy(), actions.cpu().numpy()
+        hs = np.zeros(n, np.uint32)
+        O.step_batch(hb[:4096], ha[:4096], hs[:4096], seed=SEED, step_index=0)       # load + warm
+        c0 = time.perf_counter(); passes = 0
+        while time.perf_counter() - c0 < args.cpu_seconds and passes < 1000:
+            bo, so, ro, fo = O.step_batch(hb, ha, hs, seed=SEED, step_index=W + passes, id_base=id_base)
+            passes += 1
+        csec = time.perf_counter() - c0
+        result["cpu_baseline"] = {"value": n * passes / csec, "unit": "board-steps/s", "cores": O.num_threads(),
+                                  "kind": "port",
+                                  "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
+                                            "(%.1f s, OpenMP static over boards)" % (passes, csec)}
+        # the last CPU pass doubles as a full-size parity check of what the GPU just computed
+        one_step(W + passes - 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), bo) and np.array_equal(flags.cpu().numpy(), fo), "GPU != oracle"
+        if not args.no_beam:
+            sub = 256
+            c0 = time.perf_counter()
+            oa, op, oe = O.beam_batch(roots[:sub].cpu().numpy(), BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10,
+                                      game_id_base=0)
+            csec = time.perf_counter() - c0
+            result["beam"]["cpu_baseline"] = {"value": float(oe.sum()) / csec, "unit": "expansions/s",
+                                              "cores": O.num_threads(), "kind": "port",
+                                              "sample": "%d of the 4096 roots, one decision each (%.1f s)" % (sub, csec)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

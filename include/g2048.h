@@ -1,0 +1,137 @@
+/*
+ * g2048.h -- C-ABI of the MI355X (gfx950) batched 2048 rollout / beam-search engine.
+ *
+ * The reference (vivek-tiwari-vt/2048-Using-Reinforcement-Learning) has NO FFI,
+ * plugin or operator interface: its boundary is two Python classes. This header
+ * is therefore the boundary the build defines for that hot path; each entry
+ * point names the reference method it replaces (file:line, relative to the
+ * reference root). INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. a
+ *     torch.Tensor's data_ptr()); the library allocates nothing and never
+ *     synchronises: work is enqueued on `stream` (a hipStream_t passed as
+ *     void*, NULL = the default stream) and is stream-ordered;
+ *   - a board is 16 bytes: 16 x uint8 log2 codes, row-major (0 = empty,
+ *     1 = tile 2, ... 17 = tile 131072). Board arrays must be 16-byte aligned;
+ *   - return value: 0 = G2048_OK, negative = error (g2048_last_error() gives
+ *     the text for the calling thread). Nothing throws, nothing prints;
+ *   - randomness is a counter RNG keyed by (seed, domain, step/epoch index,
+ *     GLOBAL board id, counter): results do not depend on launch geometry or
+ *     on how boards are sharded over GPUs (DESIGN.md "RNG");
+ *   - thread-safe: no global mutable state apart from the thread-local error
+ *     string.
+ * There is no CPU implementation behind this ABI: without a HIP device every
+ * compute entry point fails with G2048_ERR_HIP.
+ */
+#ifndef G2048_H
+#define G2048_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2048_ABI_VERSION 1
+
+enum {
+    G2048_OK = 0,
+    G2048_ERR_ARG = -1,        /* bad argument (null pointer, misaligned board array, bad enum) */
+    G2048_ERR_HIP = -2,        /* HIP runtime error (no device, launch failure) */
+    G2048_ERR_WORKSPACE = -3   /* workspace too small */
+};
+
+/* flags_out byte of g2048_step */
+#define G2048_FLAG_DONE        0x01u   /* game over after this step (game_2048.py:198, :279-288) */
+#define G2048_FLAG_VALID       0x02u   /* the move changed the board (game_2048.py:188)          */
+#define G2048_FLAG_MAXCODE_SHIFT 3     /* bits 3..7: max log2 code after the step -> info["highest_tile"] */
+
+/* opts of g2048_step */
+#define G2048_STEP_REWARD_F64  0x01u   /* reward_out is double[n] (parity mode); default float[n] = (float)f64 reward */
+#define G2048_STEP_AUTO_RESET  0x02u   /* finished boards are replaced by a fresh episode (score 0); flags keep DONE */
+
+/* opts of g2048_valid_moves */
+#define G2048_VALID_ENV        0x00u   /* Game2048Env.get_valid_moves semantics (game_2048.py:69-95) */
+#define G2048_VALID_AGENT      0x01u   /* BeamSearchAgent._check_valid_moves semantics, incl. its DOWN quirk
+                                          (beam_search_agent.py:183-192, :209-210 vs :251-253) */
+
+/* kind of g2048_eval */
+enum {
+    G2048_EVAL_FAST = 0,       /* BeamSearchAgent._fast_evaluate   beam_search_agent.py:280-314 */
+    G2048_EVAL_FULL = 1,       /* BeamSearchAgent._evaluate_state  beam_search_agent.py:316-403 (phase per board) */
+    G2048_EVAL_PPO_HEURISTIC = 2, /* PPOAgent.evaluate_heuristic   ppo_agent.py:271-298 */
+    G2048_EVAL_MONO_PP = 3,    /* PPOAgent.monotonicity(board, +1, +1)  ppo_agent.py:300-333 */
+    G2048_EVAL_MONO_PM = 4,    /*                        (+1, -1) */
+    G2048_EVAL_MONO_MP = 5,    /*                        (-1, +1) */
+    G2048_EVAL_MONO_MM = 6     /*                        (-1, -1) */
+};
+
+/* opts of g2048_beam_get_action */
+#define G2048_BEAM_FIXED_DOWN  0x01u   /* use the true DOWN move instead of the reference's rot180 quirk (not parity) */
+
+#define G2048_BEAM_MAX_WIDTH   32
+
+const char *g2048_last_error(void);
+int g2048_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only host); never fails */
+int g2048_device_count(void);
+
+/* Game2048Env.step for n boards (environment/game_2048.py:170-210): move, validity, spawn iff valid,
+ * shaped reward (:212-277), done (:279-288). boards_out may alias boards_in. Draw for board i:
+ * (seed, STEP, step_index, board_id_base + i). */
+int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out,
+               uint32_t *score_inout, void *reward_out, uint8_t *flags_out,
+               uint64_t seed, uint64_t step_index, uint64_t board_id_base, size_t n,
+               uint32_t opts, void *stream);
+
+/* Game2048Env.reset for n boards (environment/game_2048.py:29-48). score_out may be NULL. */
+int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch,
+                uint64_t board_id_base, size_t n, void *stream);
+
+/* get_valid_moves / _check_valid_moves: mask4_out[i] bit a = action a valid (0 LEFT 1 UP 2 RIGHT 3 DOWN). */
+int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t opts, void *stream);
+
+/* board heuristics, f64 out. phase_or_null: per-board 0 early / 1 mid / 2 late for G2048_EVAL_FULL
+ * (NULL = derive from the board's own max tile with thresholds 512 / 1024, beam_search_agent.py:271-278). */
+int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream);
+
+/* PPOAgent.normalize_state (agents/ppo_agent.py:184-195): obs_out[i*16+j] = float32(code)/float32(15). */
+int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream);
+
+/* BeamSearchAgent.get_action for n_games roots (agents/beam_search_agent.py:71-181).
+ * valid_mask_or_null: caller-supplied masks (the `valid_moves` argument), NULL = None.
+ * expanded_out_or_null: children generated per game (calls of _add_random_tile).
+ * Draw j of game g: (seed, BEAM, step_index, game_id_base + g, j) in the reference's generation order. */
+int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null,
+                          uint8_t *action_out, float *prob_out, uint32_t *expanded_out_or_null,
+                          int width, int depth, int early_threshold, int mid_threshold,
+                          uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
+                          uint32_t opts, void *stream);
+
+/* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
+int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
+int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream);
+
+/* synthetic inputs of the benchmark configs, generated on the device:
+ * each cell empty with probability p_empty_u16/65536 else code uniform in 1..max_code; an all-empty
+ * draw gets code 1 at cell 0. actions: uniform 0..3. */
+int g2048_synth_boards(void *boards_out, uint64_t seed, uint64_t board_id_base, size_t n,
+                       uint32_t p_empty_u16, uint32_t max_code, void *stream);
+int g2048_synth_actions(uint8_t *actions_out, uint64_t seed, uint64_t step_index,
+                        uint64_t board_id_base, size_t n, void *stream);
+
+/* per-shard metrics for the multi-GPU reduction: out[0] = n, out[1] = sum(score), out[2] = #done,
+ * out[3] = sum(expanded or 0), out[4..22) = histogram of max code 0..17. out must hold 24 uint64,
+ * and is accumulated into (zero it first). flags/expanded may be NULL. */
+int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flags_or_null,
+                  const uint32_t *expanded_or_null, unsigned long long *out24, size_t n, void *stream);
+
+/* device self-test of the instruction-level assumptions the kernels rely on (v_perm_b32 byte order,
+ * udot4, f64 contraction off). Writes 0 to *result_out (device uint32) when all hold. */
+int g2048_selftest(uint32_t *result_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+// hostsim.cpp -- TEST HARNESS ONLY (lives under tests/, never shipped, never loaded by the product).
+//
+// Compiles csrc/g2048_board.h -- the exact per-board arithmetic the HIP kernels run, with the three
+// gfx950 intrinsics (v_perm_b32, v_bcnt, v_dot4_u32_u8) emulated in portable C++ -- for the host CPU,
+// so the `-m "not gpu"` suite can check every SWAR routine against the oracle without a GPU. It is not
+// a CPU back-end: include/g2048.h has no entry point that reaches this code.
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "g2048_board.h"
+#include "g2048_rng.h"
+
+using namespace g2048;
+
+static Board ld(const uint8_t *p) { Board b; memcpy(b.w, p, 16); return b; }
+static void st(uint8_t *p, const Board &b) { memcpy(p, b.w, 16); }
+
+extern "C" {
+
+void hs_rng_keys(uint64_t seed, uint32_t domain, uint64_t index, uint32_t *k0, uint32_t *k1)
+{
+    const Keys k = rng_keys(seed, domain, index);
+    *k0 = k.k0; *k1 = k.k1;
+}
+
+uint32_t hs_rng_draw(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr) { return rng_draw(k0, k1, id, ctr); }
+
+void hs_move(const uint8_t *in, const uint8_t *actions, int agent, uint8_t *out, uint32_t *gain, uint8_t *valid, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const Board b = ld(in + 16 * i);
+        uint32_t g;
+        const Board o = agent ? move_agent(b, actions[i] & 3u, g, false) : move_env(b, actions[i] & 3u, g);
+        st(out + 16 * i, o); gain[i] = g; valid[i] = !same(o, b);
+    }
+}
+
+void hs_valid(const uint8_t *in, int agent, uint8_t *mask, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) mask[i] = (uint8_t)(agent ? valid_mask_agent(ld(in + 16 * i), false) : valid_mask_env(ld(in + 16 * i)));
+}
+
+void hs_spawn(const uint8_t *in, const uint32_t *h, uint8_t *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) { Board b = ld(in + 16 * i); spawn(b, h[i]); st(out + 16 * i, b); }
+}
+
+void hs_step(const uint8_t *in, const uint8_t *actions, const uint32_t *h, uint8_t *out, uint32_t *score,
+             double *reward, uint8_t *flags, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const StepOut o = step_board(ld(in + 16 * i), actions[i] & 3u, h[i]);
+        st(out + 16 * i, o.board); score[i] += o.gain; reward[i] = o.reward; flags[i] = (uint8_t)o.flags;
+    }
+}
+
+void hs_reset(const uint32_t *h0, const uint32_t *h1, uint8_t *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) st(out + 16 * i, fresh_board(h0[i], h1[i]));
+}
+
+void hs_eval(const uint8_t *in, int kind, const uint8_t *phase, double *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const Board b = ld(in + 16 * i);
+        out[i] = kind == 0 ? eval_fast(b)
+               : kind == 1 ? eval_full(b, phase ? phase[i] : phase_of(max_code(b), 512u, 1024u))
+               : kind == 2 ? eval_ppo_heuristic(b) : eval_monotonicity(b, kind - 3);
+    }
+}
+
+void hs_transpose(const uint8_t *in, uint8_t *out, uint8_t *rot, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) { st(out + 16 * i, transpose(ld(in + 16 * i))); st(rot + 16 * i, rot180(ld(in + 16 * i))); }
+}
+
+}  // extern "C"

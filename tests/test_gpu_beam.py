@@ -1,0 +1,97 @@
+"""GPU parity tests of the beam search kernel (one wavefront per game) through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as ge
+    ge.import_package()
+    from g2048 import ops as o
+    return o
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def test_beam_golden_decisions(ops):
+    """300 decisions recorded from the reference's BeamSearchAgent.get_action: (20,30) (10,15) (15,20) (3,4),
+    with and without a caller mask, incl. no-valid-move, single-move and random-fallback roots."""
+    g = load_golden("beam_decisions.npz")
+    seed, step_index = int(g["seed"]), int(g["step_index"])
+    bad = []
+    for i in range(g["root"].shape[0]):
+        mask = None if g["mask"][i] < 0 else torch.tensor([int(g["mask"][i])], dtype=torch.uint8, device=DEV)
+        a, p = ops.beam_get_action(dev(g["root"][i:i + 1]), int(g["width"][i]), int(g["depth"][i]), mask,
+                                   seed=seed, step_index=step_index, game_id_base=int(g["game_id"][i]))
+        if int(a.item()) != g["action"][i] or float(p.item()) != g["prob"][i]:
+            bad.append(i)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("width,depth", [(20, 30), (10, 15), (32, 12), (1, 6), (16, 30)])
+def test_beam_batch_vs_oracle(ops, oracle, width, depth):
+    """Config 3 shape: 4096 concurrent games; actions, probabilities and expansion counts vs the oracle."""
+    n = 4096 if (width, depth) == (20, 30) else 1024
+    hb = np.concatenate([oracle.synth_boards(n // 2, seed=51), oracle.synth_boards(n - n // 2, seed=52, p_empty=0.1, max_code=6)])
+    roots = dev(hb)
+    a, p, e = ops.beam_get_action(roots, width, depth, seed=99, step_index=7, game_id_base=1000, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(hb, width, depth, seed=99, step_index=7, game_id_base=1000)
+    assert np.array_equal(a.cpu().numpy(), oa)
+    assert np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+    assert len(set(oa.tolist())) == 4
+
+
+def test_beam_with_caller_masks_and_thresholds(ops, oracle):
+    n = 2048
+    hb = oracle.synth_boards(n, seed=61, p_empty=0.25, max_code=12)
+    env_mask = oracle.valid_moves_batch(hb, False)
+    a, p, e = ops.beam_get_action(dev(hb), 12, 18, dev(env_mask), early_threshold=256, mid_threshold=2048,
+                                  seed=5, step_index=1, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(hb, 12, 18, mask=env_mask, early_thr=256, mid_thr=2048, seed=5, step_index=1)
+    assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+
+
+def test_drop_in_classes_train_loop(ops, oracle):
+    """A train.py-shaped loop (reference train.py:48-107) over the look-alike classes; every transition is
+    replayed through the oracle with the same draw schedule."""
+    from environment.game_2048 import Game2048Env
+    from agents.beam_search_agent import BeamSearchAgent
+    env = Game2048Env(seed=1234)
+    agent = BeamSearchAgent(beam_width=8, search_depth=10, seed=77)
+    state = env.reset()
+    assert state.dtype == np.int32 and state.shape == (16,)
+    k0, k1 = oracle.rng_keys(1234, oracle.DOM_STEP, 0)
+    score = 0
+    for step in range(60):
+        valid_moves = env.get_valid_moves()
+        assert isinstance(valid_moves, list) and all(isinstance(v, bool) for v in valid_moves)
+        assert valid_moves == [bool((oracle.env_valid_mask(state) >> a) & 1) for a in range(4)]
+        action, prob = agent.get_action(state, valid_moves)
+        assert isinstance(action, int) and isinstance(prob, float)
+        ref = oracle.beam_get_action(state, sum(int(v) << a for a, v in enumerate(valid_moves)), 8, 10,
+                                     seed=77, step_index=step, game_id=0)
+        assert (action, prob) == (ref["action"], ref["prob"])
+        next_state, reward, done, info = env.step(action)
+        k0, k1 = oracle.rng_keys(1234, oracle.DOM_STEP, step)
+        b, score, r, d, v, hi = oracle.env_step(state, score, action, oracle.rng_draw(k0, k1, 0, 0))
+        assert np.array_equal(next_state, b) and reward == r and done == d
+        assert isinstance(reward, np.float64) and isinstance(done, bool)
+        assert info["score"] == score and info["valid_move"] == v and info["highest_tile"] == hi
+        assert np.array_equal(env.board, b.reshape(4, 4)) and env.board.dtype == np.int32
+        state = next_state
+        if done:
+            break
+    env.board = np.array([[2, 2, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 4]], dtype=np.int32)
+    assert env.get_valid_moves() == [True, True, True, True]
+    s, r, d, info = env.step(0)
+    assert s[0] == 4 and info["valid_move"]

@@ -1,0 +1,230 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (g2048.ops -> csrc/libg2048_hip.so), against
+the committed golden vectors (captured from the reference) and against the CPU oracle on the same seeded
+inputs. Bit-exact for boards / scores / flags / masks; f64 `==` for rewards and heuristic scores (the
+north star allows 1e-6; the tolerance used here is 0). Full-size cases use the BASELINE configs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, tiles_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SEED = 0x2048
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as ge
+    ge.import_package()
+    from g2048 import ops as o, _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def test_selftest_instruction_assumptions(ops):
+    assert ops.selftest(DEV) == 0
+
+
+def test_native_library_is_loaded(ops):
+    import os
+    from g2048 import _lib
+    maps = open("/proc/self/maps").read()
+    assert os.path.basename(_lib.library_path()) in maps
+
+
+def test_synth_inputs_match_oracle(ops, oracle):
+    n = 100003
+    b = ops.synth_boards(n, seed=SEED, id_base=12345, device=DEV)
+    a = ops.synth_actions(n, seed=SEED, step_index=9, id_base=12345, device=DEV)
+    assert np.array_equal(host(b), oracle.synth_boards(n, seed=SEED, id_base=12345))
+    assert np.array_equal(host(a), oracle.synth_actions(n, seed=SEED, step_index=9, id_base=12345))
+    b2 = ops.synth_boards(4096, seed=3, id_base=2**40, p_empty=0.05, max_code=17, device=DEV)
+    assert np.array_equal(host(b2), oracle.synth_boards(4096, seed=3, id_base=2**40, p_empty=0.05, max_code=17))
+
+
+def test_step_golden_transitions(ops):
+    """8.8k transitions recorded from the reference (incl. invalid moves, dead/full/empty boards)."""
+    g = load_golden("step_transitions.npz")
+    b, a = dev(g["board_in"]), dev(g["action"])
+    sc = dev(g["score_in"].astype(np.int32))
+    out, rw, fl = ops.step(b, a, sc, seed=SEED, step_index=5, id_base=0, reward_f64=True)
+    fl = host(fl)
+    assert np.array_equal(host(out), g["board_out"])
+    assert np.array_equal(host(sc), g["score_out"])
+    assert np.array_equal(host(rw), g["reward"], equal_nan=True)            # f64 ==
+    assert np.array_equal(fl & 1, g["done"]) and np.array_equal((fl >> 1) & 1, g["valid"])
+    assert np.array_equal(1 << (fl >> 3).astype(np.int64), np.maximum(g["highest_tile"], 1))
+    # f32 reward mode = (float) of the f64 reward
+    sc2 = dev(g["score_in"].astype(np.int32))
+    _, rw32, _ = ops.step(b, a, sc2, seed=SEED, step_index=5, id_base=0)
+    assert np.array_equal(host(rw32), g["reward"].astype(np.float32), equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1048576])
+def test_step_vs_oracle_sizes(ops, oracle, n):
+    """Config 2 (1,048,576 boards, all four actions in one launch) and ragged sizes."""
+    b = ops.synth_boards(n, seed=SEED, device=DEV)
+    a = ops.synth_actions(n, seed=SEED, step_index=1, device=DEV)
+    sc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, seed=SEED, step_index=1, reward_f64=True)
+    bo, so, ro, fo = oracle.step_batch(host(b), host(a), np.zeros(n, np.uint32), seed=SEED, step_index=1)
+    assert np.array_equal(host(out), bo)
+    assert np.array_equal(host(sc).astype(np.uint32), so)
+    assert np.array_equal(host(rw), ro, equal_nan=True)
+    assert np.array_equal(host(fl), fo)
+    if n >= 1000:
+        assert set(np.unique(host(a))) == {0, 1, 2, 3}
+
+
+def test_step_in_place_and_auto_reset(ops, oracle):
+    n = 50000
+    hb = oracle.synth_boards(n, seed=5, p_empty=0.02, max_code=3)       # dense: many boards die
+    ha = oracle.synth_actions(n, seed=5, step_index=0)
+    b = dev(hb); sc = torch.full((n,), 100, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, dev(ha), sc, seed=5, step_index=0, out=b, reward_f64=True, auto_reset=True)
+    assert out.data_ptr() == b.data_ptr()
+    bo, so, ro, fo = oracle.step_batch(hb, ha, np.full(n, 100, np.uint32), seed=5, step_index=0, opts=1)
+    assert (fo & 1).sum() > 100
+    assert np.array_equal(host(b), bo) and np.array_equal(host(sc).astype(np.uint32), so)
+    assert np.array_equal(host(rw), ro, equal_nan=True) and np.array_equal(host(fl), fo)
+
+
+def test_reset_vs_oracle_and_golden(ops, oracle):
+    b, sc = ops.reset(70001, seed=SEED, epoch=3, id_base=77, device=DEV)
+    ob, osc = oracle.reset_batch(70001, seed=SEED, epoch=3, id_base=77)
+    assert np.array_equal(host(b), ob) and int(sc.abs().sum()) == 0
+    g = load_golden("episodes.npz")
+    b1, _ = ops.reset(1, seed=int(g["seed"]), epoch=0, id_base=0, device=DEV)
+    assert np.array_equal(host(b1)[0], g["c1_board0"])
+    for e in range(4):
+        be, _ = ops.reset(1, seed=int(g["seed"]), epoch=0, id_base=e, device=DEV)
+        assert np.array_equal(host(be)[0], g["ep%d_board0" % e])
+
+
+def test_valid_moves_both_semantics(ops, oracle):
+    g = load_golden("moves.npz")
+    b = dev(g["board"])
+    assert np.array_equal(host(ops.valid_moves(b, False)), g["env_mask"])
+    assert np.array_equal(host(ops.valid_moves(b, True)), g["agent_mask"])
+    big = ops.synth_boards(300000, seed=11, p_empty=0.1, max_code=4, device=DEV)
+    for agent in (False, True):
+        assert np.array_equal(host(ops.valid_moves(big, agent)), oracle.valid_moves_batch(host(big), agent))
+
+
+def test_eval_kernels(ops, oracle):
+    from g2048 import _lib as L
+    g = load_golden("eval_scores.npz")
+    b = dev(g["board"]); n = b.shape[0]
+    assert np.array_equal(host(ops.evaluate(b, L.EVAL_FAST)), g["fast"])
+    for p in range(3):
+        ph = torch.full((n,), p, dtype=torch.uint8, device=DEV)
+        assert np.array_equal(host(ops.evaluate(b, L.EVAL_FULL, ph)), g["full"][:, p])       # f64 ==
+    assert np.array_equal(host(ops.evaluate(b, L.EVAL_FULL)), g["full"][np.arange(n), g["phase"]])
+    assert np.array_equal(host(ops.evaluate(b, L.EVAL_PPO_HEURISTIC)), g["ppo_heuristic"])
+    for k in range(4):
+        assert np.array_equal(host(ops.evaluate(b, L.EVAL_MONO_PP + k)), g["monotonicity"][:, k])
+    assert np.array_equal(host(ops.obs(b)).view(np.uint32), g["normalize"].view(np.uint32))   # f32 bits
+    big = ops.synth_boards(200000, seed=13, p_empty=0.2, max_code=15, device=DEV)
+    hb = host(big)
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_FAST)), oracle.eval_batch(hb, oracle.EVAL_FAST))
+    ph = (torch.arange(200000, device=DEV) % 3).to(torch.uint8)
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_FULL, ph)), oracle.eval_batch(hb, oracle.EVAL_FULL, host(ph)))
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_PPO_HEURISTIC)), oracle.eval_batch(hb, oracle.EVAL_PPO))
+    assert np.array_equal(host(ops.obs(big)), oracle.obs_batch(hb))
+
+
+def test_pack_unpack_roundtrip(ops, oracle):
+    b = ops.synth_boards(65537, seed=17, p_empty=0.3, max_code=17, device=DEV)
+    t = ops.unpack(b)
+    assert np.array_equal(host(t), oracle.unpack(host(b)))
+    assert np.array_equal(host(ops.pack(t)), host(b))
+
+
+def test_config1_trace_through_vec_env(ops):
+    """Config 1: one board, reset, 1000 hashed actions, auto-reset -- must equal what the reference did."""
+    from g2048 import VecGame2048
+    g = load_golden("episodes.npz")
+    env = VecGame2048(1, device=DEV, seed=int(g["seed"]), auto_reset=True, reward_f64=True)
+    assert np.array_equal(host(env.boards)[0], g["c1_board0"])
+    boards, rewards, dones, scores = [], [], [], []
+    for t in range(1000):
+        a = env.random_actions()
+        assert int(a.item()) == g["c1_action"][t]
+        b, r, d, info = env.step(a)
+        boards.append(b.clone()); rewards.append(r.clone()); dones.append(d.clone()); scores.append(info["score"].clone())
+    assert np.array_equal(host(torch.cat(boards)), g["c1_board"])
+    assert np.array_equal(host(torch.cat(rewards)), g["c1_reward"])
+    assert np.array_equal(host(torch.cat(dones)).astype(np.uint8), g["c1_done"])
+    exp_score = np.where(g["c1_done"] == 1, 0, g["c1_score"])
+    assert np.array_equal(host(torch.cat(scores)), exp_score)
+
+
+def test_full_episodes_replay(ops):
+    g = load_golden("episodes.npz")
+    for e in range(4):
+        b, sc = ops.reset(1, seed=int(g["seed"]), epoch=0, id_base=e, device=DEV)
+        for t in range(g["ep%d_action" % e].shape[0]):
+            a = dev(g["ep%d_action" % e][t:t + 1])
+            b, r, fl = ops.step(b, a, sc, seed=int(g["seed"]), step_index=t, id_base=e, reward_f64=True)
+            assert np.array_equal(host(b)[0], g["ep%d_board" % e][t]), (e, t)
+            assert float(r.item()) == g["ep%d_reward" % e][t], (e, t)
+            assert (int(fl.item()) & 1) == g["ep%d_done" % e][t] and int(sc.item()) == g["ep%d_score" % e][t]
+
+
+def test_step_properties_full_size(ops):
+    """Size-independent properties on 1,048,576 boards: tile-sum conservation (+ the spawned tile),
+    valid <=> board changed before the spawn, done <=> no valid move afterwards, invalid => no spawn."""
+    n = 1 << 20
+    b = ops.synth_boards(n, seed=21, device=DEV)
+    a = ops.synth_actions(n, seed=21, step_index=0, device=DEV)
+    sc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, seed=21, step_index=0)
+    tin, tout = ops.unpack(b).sum(dim=1), ops.unpack(out).sum(dim=1)
+    valid = (fl & 2).bool()
+    diff = tout - tin
+    assert bool(((diff == 2) | (diff == 4))[valid].all()) and bool((diff == 0)[~valid].all())
+    assert bool((out == b).all(dim=1)[~valid].all())
+    mask_before = ops.valid_moves(b)
+    assert bool((((mask_before >> a) & 1).bool() == valid).all())
+    assert bool(((ops.valid_moves(out) == 0) == (fl & 1).bool()).all())
+    frac4 = float((diff[valid] == 4).float().mean())
+    assert 0.09 < frac4 < 0.11
+    assert bool((sc >= 0).all()) and bool((sc % 4 == 0).all())
+
+
+def test_sharding_invariance(ops):
+    """Results keyed by GLOBAL board id: one launch over n boards == two launches over the halves."""
+    n = 200000
+    b = ops.synth_boards(n, seed=31, device=DEV)
+    a = ops.synth_actions(n, seed=31, step_index=4, device=DEV)
+    sc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, seed=31, step_index=4, reward_f64=True)
+    h = n // 2
+    for lo, hi in ((0, h), (h, n)):
+        bs = ops.synth_boards(hi - lo, seed=31, id_base=lo, device=DEV)
+        as_ = ops.synth_actions(hi - lo, seed=31, step_index=4, id_base=lo, device=DEV)
+        scs = torch.zeros(hi - lo, dtype=torch.int32, device=DEV)
+        o2, r2, f2 = ops.step(bs, as_, scs, seed=31, step_index=4, id_base=lo, reward_f64=True)
+        assert bool((o2 == out[lo:hi]).all()) and bool((r2 == rw[lo:hi]).all()) and bool((f2 == fl[lo:hi]).all())
+
+
+def test_metrics_kernel(ops):
+    n = 123457
+    b = ops.synth_boards(n, seed=41, device=DEV)
+    sc = (torch.arange(n, device=DEV) % 1000).to(torch.int32)
+    fl = (torch.arange(n, device=DEV) % 7 == 0).to(torch.uint8)
+    m = host(ops.metrics(b, sc, fl))
+    assert m[0] == n and m[1] == int(sc.sum()) and m[2] == int(fl.sum())
+    hist = np.bincount(host(b).max(axis=1), minlength=18)
+    assert np.array_equal(m[4:22], hist)
