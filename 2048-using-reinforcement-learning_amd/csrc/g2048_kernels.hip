@@ -39,6 +39,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
 constexpr int kBlock = 256;
+constexpr int kStepBoardsPerLane = 1;     // default of g2048_step: measured fastest (profiles/r01_step_tune.txt)
 inline unsigned blocks_for(size_t n, int per_block = kBlock) { return (unsigned)((n + per_block - 1) / per_block); }
 
 __device__ __forceinline__ Board load_board(const uint4 *p, size_t i)
@@ -53,8 +54,12 @@ __device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
 }
 
 // ------------------------------------------------------------------ step ------
-// Game2048Env.step (environment/game_2048.py:170-210) for one board per lane.
-template <bool REWARD_F64, bool AUTO_RESET>
+// Game2048Env.step (environment/game_2048.py:170-210), one board per lane per pass, B passes per lane.
+// All B loads of a lane are issued before the first board is computed: with ~400 VALU instructions per
+// board the kernel sits between the HBM and the VALU roofline, and a wave that only ever has one board
+// in flight serialises load latency -> compute -> store. A block owns 256*B consecutive boards; pass k
+// of a wave touches 64 consecutive boards (1 KiB per wave-instruction).
+template <bool REWARD_F64, bool AUTO_RESET, int B>
 __global__ __launch_bounds__(kBlock) void step_kernel(const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
                                                      uint4 *boards_out,
@@ -64,29 +69,37 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const uint4 *boards_in,   
                                                      uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
                                                      uint64_t id_base, size_t n)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const Board prev = load_board(boards_in, i);
-    const uint32_t action = actions[i] & 3u;
-    uint32_t sc = score[i];
-
-    const StepOut o = step_board(prev, action, rng_draw(k0, k1, id_base + i, 0u));
-    Board cur = o.board;
-    sc += o.gain;
-    const uint8_t fl = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
-    const bool done = (o.flags & G2048_FLAG_DONE) != 0u;
-    const double r = o.reward;
-    if (AUTO_RESET) {
-        if (done) {
-            cur = fresh_board(rng_draw(e0, e1, id_base + i, 0u), rng_draw(e0, e1, id_base + i, 1u));
-            sc = 0u;
+    const size_t base = (size_t)blockIdx.x * (kBlock * B) + threadIdx.x;
+    Board prev[B];
+    uint32_t action[B], sc[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const size_t i = base + (size_t)k * kBlock;
+        if (i < n) {
+            prev[k] = load_board(boards_in, i);
+            action[k] = actions[i];
+            sc[k] = score[i];
         }
     }
-    store_board(boards_out, i, cur);
-    score[i] = sc;
-    if (REWARD_F64) static_cast<double *>(reward_out)[i] = r;
-    else static_cast<float *>(reward_out)[i] = (float)r;
-    flags_out[i] = fl;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const size_t i = base + (size_t)k * kBlock;
+        if (i >= n) break;
+        const StepOut o = step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id_base + i, 0u));
+        Board cur = o.board;
+        uint32_t s = sc[k] + o.gain;
+        if (AUTO_RESET) {
+            if (o.flags & G2048_FLAG_DONE) {
+                cur = fresh_board(rng_draw(e0, e1, id_base + i, 0u), rng_draw(e0, e1, id_base + i, 1u));
+                s = 0u;
+            }
+        }
+        store_board(boards_out, i, cur);
+        score[i] = s;
+        if (REWARD_F64) static_cast<double *>(reward_out)[i] = o.reward;
+        else static_cast<float *>(reward_out)[i] = (float)o.reward;
+        flags_out[i] = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
+    }
 }
 
 // ------------------------------------------------------------------ reset -----
@@ -255,20 +268,26 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, 
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
-    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET)) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | (3u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
     const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(blocks_for(n)), block(kBlock);
+    const dim3 block(kBlock);
     const uint4 *in = static_cast<const uint4 *>(boards_in);
     uint4 *out = static_cast<uint4 *>(boards_out);
     const bool f64 = opts & G2048_STEP_REWARD_F64, ar = opts & G2048_STEP_AUTO_RESET;
-#define G2048_LAUNCH_STEP(F, A) \
-    hipLaunchKernelGGL((step_kernel<F, A>), grid, block, 0, s, in, actions, out, score_inout, reward_out, flags_out, \
-                       k.k0, k.k1, e.k0, e.k1, board_id_base, n)
-    if (f64 && ar) G2048_LAUNCH_STEP(true, true);
-    else if (f64) G2048_LAUNCH_STEP(true, false);
-    else if (ar) G2048_LAUNCH_STEP(false, true);
-    else G2048_LAUNCH_STEP(false, false);
+    const unsigned tune = (opts >> G2048_STEP_TUNE_SHIFT) & 3u;            // 0 = default
+    const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : kStepBoardsPerLane;
+#define G2048_LAUNCH_STEP(F, A, BB) \
+    hipLaunchKernelGGL((step_kernel<F, A, BB>), dim3(blocks_for(n, kBlock * BB)), block, 0, s, in, actions, out, \
+                       score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n)
+#define G2048_LAUNCH_STEP_B(F, A) \
+    do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
+         else G2048_LAUNCH_STEP(F, A, 4); } while (0)
+    if (f64 && ar) G2048_LAUNCH_STEP_B(true, true);
+    else if (f64) G2048_LAUNCH_STEP_B(true, false);
+    else if (ar) G2048_LAUNCH_STEP_B(false, true);
+    else G2048_LAUNCH_STEP_B(false, false);
+#undef G2048_LAUNCH_STEP_B
 #undef G2048_LAUNCH_STEP
     return check_launch("g2048_step");
 }

@@ -1,0 +1,77 @@
+"""Multi-GPU plumbing: independent shards, one process per GPU, one collective at the end.
+
+Boards (and beam-search games) are independent and every random draw is keyed by the GLOBAL board id,
+so the path shards by contiguous id ranges with no data-path collective. What is exchanged is
+only the final per-board scores (all-gather, 4 MiB per rank at 1,048,576 boards) and the small metrics
+vector (all-reduce). Backend: "nccl" (= RCCL over xGMI) on GPUs; the same code runs on "gloo" for the
+CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None, device=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    w, r, lr = world()
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return w, r, lr
+
+
+def shard(n_global, rank, world_size):
+    """Contiguous range [lo, hi) of the global board ids owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(n_global), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def all_gather_scores(scores):
+    """Per-board scores of every shard, in global id order. Equal shard sizes (the benchmark's case) use one
+    all_gather_into_tensor; ragged shards fall back to all_gather of padded tensors."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return scores.clone()
+    w = dist.get_world_size()
+    n = torch.tensor([scores.numel()], dtype=torch.int64, device=scores.device)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    if len(set(sizes)) == 1:
+        out = torch.empty(w * sizes[0], dtype=scores.dtype, device=scores.device)
+        dist.all_gather_into_tensor(out, scores.contiguous())
+        return out
+    m = max(sizes)
+    padded = torch.zeros(m, dtype=scores.dtype, device=scores.device)
+    padded[:scores.numel()] = scores
+    parts = [torch.empty_like(padded) for _ in range(w)]
+    dist.all_gather(parts, padded)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)])
+
+
+def reduce_metrics(metrics):
+    """Sum of the per-shard metric vectors (g2048_metrics layout) over all ranks, in place."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+    return metrics
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -59,15 +59,11 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
         args.gpus = world
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
     ge.import_package()
-    from g2048 import ops, _lib
+    from g2048 import ops, _lib, dist as gdist
+    gdist.init("nccl", dev)
     _lib.lib()
     assert ops.selftest(dev) == 0, "device self-test failed"
 
@@ -83,9 +79,7 @@ def main():
     def one_step(t):
         ops.step(boards, actions, scores, SEED, t, id_base, out=out, reward=reward, flags=flags)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = gdist.barrier
 
     K, W = args.steps, args.warmup
     for t in range(W):
@@ -105,51 +99,47 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps -------------------------------------------------
+    # wall clock between barrier + synchronize pairs (-> value), and a HIP event pair on the launch
+    # stream around the same K launches (-> average launch duration for the roofline)
     scores.zero_()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     if graph is not None:
         graph.replay()
     else:
         for t in range(K):
             one_step(W + t)
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / K
+    elapsed = gdist.max_over_ranks(elapsed, dev)
 
     # ---- final metrics reduction: all-gather of per-board scores (config 5), timed separately
     gather_ms = None
     if world > 1:
-        gathered = torch.empty(world * n, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, scores)
+        gathered = gdist.all_gather_scores(scores)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert bool((gathered[rank * n:(rank + 1) * n] == scores).all())
-        m = ops.metrics(out, scores, flags)
-        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        assert gathered.numel() == world * n and bool((gathered[rank * n:(rank + 1) * n] == scores).all())
+        m = gdist.reduce_metrics(ops.metrics(out, scores, flags))
         assert int(m[0].item()) == world * n
 
-    # ---- roofline leg: the step kernel, launch by launch, HIP events on the launch stream ---
-    reps = min(max(K, 50), 400)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for t in range(reps):
-        evs[t][0].record()
-        one_step(W + t)
-        evs[t][1].record()
-    torch.cuda.synchronize()
-    durs = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3          # seconds
-    kernel_s = float(np.mean(durs))
+    # ---- roofline: algorithmic bytes per launch / average launch duration over the timed region ----
     achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_step.json")     # HBM bytes per launch from the rocprofv3 PMC passes
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
 
     result = {
         "metric": "board-steps/sec (batched env.step)",
@@ -167,10 +157,10 @@ def main():
                    "boards_per_gpu": n, "launch": "hipGraph of K launches" if graph is not None else "eager",
                    "parallelism": "%d shard(s) of 1,048,576 boards, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "step_kernel<false,false>", "kernel_us": kernel_s * 1e6,
-                     "kernel_us_min": float(durs.min()) * 1e6,
-                     "algorithmic_bytes_per_launch": n * STEP_BYTES_F32},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "step_kernel<false,false,1>", "kernel_us": kernel_s * 1e6,
+                     "algorithmic_bytes_per_launch": n * STEP_BYTES_F32,
+                     "timing": "HIP event pair on the launch stream around the K timed launches / K"},
     }
     if gather_ms is not None:
         result["allgather_scores_ms"] = gather_ms
@@ -203,8 +193,10 @@ def main():
 
     # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
         from oracle import oracle as O
+        # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the
+        # box's CPU share (16 for one GPU) or to the cores this process may run on, whichever is smaller
+        O.set_num_threads(min(16, len(os.sched_getaffinity(0))))
         hb, ha = boards.cpu().numpy(), actions.cpu().numpy()
         hs = np.zeros(n, np.uint32)
         O.step_batch(hb[:4096], ha[:4096], hs[:4096], seed=SEED, step_index=0)       # load + warm
@@ -234,6 +226,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

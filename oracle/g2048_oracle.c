@@ -657,6 +657,15 @@ void g2048o_beam_batch(const uint8_t *roots, const uint8_t *mask_or_null, uint8_
     }
 }
 
+void g2048o_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int g2048o_num_threads(void)
 {
 #ifdef _OPENMP

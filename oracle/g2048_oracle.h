@@ -95,6 +95,7 @@ void g2048o_beam_batch(const uint8_t *roots, const uint8_t *mask_or_null, uint8_
                        int32_t early_thr, int32_t mid_thr,
                        uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n);
 int  g2048o_num_threads(void);
+void g2048o_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ def lib():
             "g2048o_beam_batch": (None, [u8p, u8p, u8p, f32p, u32p, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                          C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
             "g2048o_num_threads": (C.c_int, []),
+            "g2048o_set_num_threads": (None, [C.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -277,3 +278,7 @@ def beam_batch(roots, width, depth, mask=None, early_thr=512, mid_thr=1024, seed
 
 def num_threads():
     return lib().g2048o_num_threads()
+
+
+def set_num_threads(n):
+    lib().g2048o_set_num_threads(int(n))

@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo. Each rank steps its own contiguous shard of the global board range
+(here through the oracle, standing in for the GPU) with id_base = shard start, then the product's
+g2048.dist helpers gather the scores and reduce the metrics. The union must equal a single-process run over
+all boards -- the multi-GPU correctness property (results keyed by global board id)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, REPO
+
+N_GLOBAL = 20001      # odd on purpose: ragged shards
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2048 import dist as gdist
+    from oracle import oracle as O
+    O.set_num_threads(1)
+    w, r, _ = gdist.init("gloo")
+    assert (w, r) == (world, rank)
+    lo, hi = gdist.shard(N_GLOBAL, rank, world)
+    b = O.synth_boards(hi - lo, seed=3, id_base=lo)
+    a = O.synth_actions(hi - lo, seed=3, step_index=2, id_base=lo)
+    bo, sc, rw, fl = O.step_batch(b, a, np.zeros(hi - lo, np.uint32), seed=3, step_index=2, id_base=lo)
+    scores = torch.from_numpy(sc.astype(np.int32))
+    gathered = gdist.all_gather_scores(scores)
+    m = torch.zeros(24, dtype=torch.int64)
+    m[0], m[1], m[2] = hi - lo, int(sc.sum()), int((fl & 1).sum())
+    gdist.reduce_metrics(m)
+    t = gdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    gdist.barrier()
+    if rank == 0:
+        q.put((gathered.numpy(), m.numpy(), t))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_union_equals_single_run(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered, m, t = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = oracle.synth_boards(N_GLOBAL, seed=3)
+    a = oracle.synth_actions(N_GLOBAL, seed=3, step_index=2)
+    bo, sc, rw, fl = oracle.step_batch(b, a, np.zeros(N_GLOBAL, np.uint32), seed=3, step_index=2)
+    assert np.array_equal(gathered.astype(np.uint32), sc)
+    assert m[0] == N_GLOBAL and m[1] == int(sc.sum()) and m[2] == int((fl & 1).sum())
+    assert t == 2.0
+
+
+def test_shard_ranges_cover_exactly():
+    sys.path.insert(0, PKG)
+    from g2048 import dist as gdist
+    for n in (0, 1, 7, 8, 1 << 20, 8388608, 8388609):
+        for w in (1, 2, 3, 8):
+            r = [gdist.shard(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1

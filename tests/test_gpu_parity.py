@@ -88,14 +88,14 @@ def test_step_vs_oracle_sizes(ops, oracle, n):
 
 
 def test_step_in_place_and_auto_reset(ops, oracle):
-    n = 50000
+    n = 200000
     hb = oracle.synth_boards(n, seed=5, p_empty=0.02, max_code=3)       # dense: many boards die
     ha = oracle.synth_actions(n, seed=5, step_index=0)
     b = dev(hb); sc = torch.full((n,), 100, dtype=torch.int32, device=DEV)
     out, rw, fl = ops.step(b, dev(ha), sc, seed=5, step_index=0, out=b, reward_f64=True, auto_reset=True)
     assert out.data_ptr() == b.data_ptr()
     bo, so, ro, fo = oracle.step_batch(hb, ha, np.full(n, 100, np.uint32), seed=5, step_index=0, opts=1)
-    assert (fo & 1).sum() > 100
+    assert (fo & 1).sum() > 50
     assert np.array_equal(host(b), bo) and np.array_equal(host(sc).astype(np.uint32), so)
     assert np.array_equal(host(rw), ro, equal_nan=True) and np.array_equal(host(fl), fo)
 
