@@ -1,0 +1,127 @@
+"""Batched evaluation driver: many beam-search games played to completion, resident on the GPU.
+
+Device-resident version of the reference's evaluation loops --
+`run_evaluation.evaluate_beam_search` (run_evaluation.py:48-130) and
+`evaluate_beam_search.run_game / run_evaluation` (evaluate_beam_search.py:16-217): every game does
+`action = agent.get_action(state)` (no caller mask, so the agent's own validity check applies,
+run_evaluation.py:62) then `env.step(action)` until done or the move cap (5000, run_evaluation.py:67).
+Here all games advance together: one `g2048_beam_get_action` launch (one wavefront per game) and one
+`g2048_step` launch per move, no host round trip except an "all finished?" poll every `check_every` moves.
+Finished games stay in the batch as no-ops (their counters are frozen), so ids -- and therefore every random
+draw -- never change: game g at move t always uses draws (seed, BEAM|STEP, t, game_id_base + g).
+
+The result dict has the keys of both reference drivers (scores, highest_tiles, moves, valid_moves,
+invalid_moves, milestones, best_games, final_boards, best_board, best_score, best_game_idx) and
+`save_overall_results` writes the reference's overall_results.json schema (evaluate_beam_search.py:198-214).
+"""
+import json
+import time
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .vec import VecGame2048
+
+MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_search.py:42-43
+
+
+def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
+                         device="cuda", game_id_base=0, check_every=64, early_game_threshold=512,
+                         mid_game_threshold=1024, fixed_down=False):
+    dev = torch.device(device)
+    n = int(num_games)
+    t_start = time.perf_counter()
+    env = VecGame2048(n, device=dev, seed=seed, id_base=game_id_base)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    moves = torch.zeros(n, dtype=torch.int32, device=dev)
+    valid_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    invalid_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms_codes = torch.tensor([m.bit_length() - 1 for m in MILESTONES], dtype=torch.uint8, device=dev)
+    ms_move = torch.full((n, len(MILESTONES)), -1, dtype=torch.int32, device=dev)
+    expanded_total = torch.zeros((), dtype=torch.int64, device=dev)
+    t = 0
+    while t < max_moves:
+        actions, _, expanded = ops.beam_get_action(env.boards, beam_width, search_depth, None, early_game_threshold,
+                                                   mid_game_threshold, seed, t, game_id_base, fixed_down,
+                                                   want_expanded=True)
+        _, _, done, _ = env.step(actions)
+        flags = env.flags
+        maxcode = flags >> L.FLAG_MAXCODE_SHIFT
+        valid = (flags & L.FLAG_VALID).bool()
+        hit = alive[:, None] & (ms_move < 0) & (maxcode[:, None] >= ms_codes[None, :])     # evaluate_beam_search.py:60-64
+        ms_move = torch.where(hit, torch.full_like(ms_move, t), ms_move)
+        valid_cnt += (alive & valid).int()
+        invalid_cnt += (alive & ~valid).int()
+        expanded_total += (expanded.long() * alive.long()).sum()
+        moves += alive.int()
+        alive = alive & ~done
+        t += 1
+        if t % check_every == 0 and not bool(alive.any()):
+            break
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t_start
+
+    scores = env.scores.cpu().numpy().astype("int64")
+    final_boards = ops.unpack(env.boards).cpu().numpy().reshape(n, 4, 4)
+    highest = final_boards.reshape(n, 16).max(axis=1)
+    ms_host = ms_move.cpu().numpy()
+    order = sorted(range(n), key=lambda i: scores[i], reverse=True)       # stable, like the reference's top-5 update
+    best = int(order[0]) if n else 0
+    results = {
+        "scores": [int(s) for s in scores],
+        "highest_tiles": [int(h) for h in highest],
+        "moves": [int(m) for m in moves.cpu().numpy()],
+        "valid_moves": [int(m) for m in valid_cnt.cpu().numpy()],
+        "invalid_moves": [int(m) for m in invalid_cnt.cpu().numpy()],
+        "milestones": {m: [int(v) for v in ms_host[:, k] if v >= 0] for k, m in enumerate(MILESTONES)},
+        "best_games": [int(i) for i in order[:5]],
+        "final_boards": final_boards,
+        "best_board": final_boards[best].copy() if n else None,
+        "best_score": int(scores[best]) if n else 0,
+        "best_game_idx": best,
+        "unfinished": int(alive.sum().item()),
+        "total_moves": int(moves.sum().item()),
+        "total_expansions": int(expanded_total.item()),
+        "elapsed_s": elapsed,
+        "parameters": {"beam_width": beam_width, "search_depth": search_depth, "num_games": n, "seed": seed,
+                       "max_moves": max_moves},
+    }
+    results["summary"] = summarize(results)
+    return results
+
+
+def summarize(results):
+    """The numbers the reference prints / reports (run_evaluation.py:110-128, report.md)."""
+    n = max(len(results["scores"]), 1)
+    tiles = results["highest_tiles"]
+    dist = {}
+    for tile in tiles:
+        dist[tile] = dist.get(tile, 0) + 1
+    return {
+        "games": len(results["scores"]),
+        "highest_tile": max(tiles) if tiles else 0,
+        "best_score": max(results["scores"]) if tiles else 0,
+        "average_score": sum(results["scores"]) / n,
+        "average_highest_tile": sum(tiles) / n,
+        "rate_2048_or_more": sum(1 for x in tiles if x >= 2048) / n,
+        "tile_distribution_pct": {int(k): 100.0 * v / n for k, v in sorted(dist.items())},
+        "hit_move_cap": results.get("unfinished", 0),
+        "moves_per_s": results["total_moves"] / results["elapsed_s"] if results.get("elapsed_s") else None,
+        "expansions_per_s": results["total_expansions"] / results["elapsed_s"] if results.get("elapsed_s") else None,
+    }
+
+
+def save_overall_results(results, path):
+    """overall_results.json with the reference's keys (evaluate_beam_search.py:198-214)."""
+    p = results["parameters"]
+    out = {
+        "scores": results["scores"], "highest_tiles": results["highest_tiles"], "moves": results["moves"],
+        "valid_moves": results["valid_moves"], "invalid_moves": results["invalid_moves"],
+        "milestones": {str(k): v for k, v in results["milestones"].items()},
+        "best_games": results["best_games"],
+        "parameters": {"beam_width": p["beam_width"], "search_depth": p["search_depth"], "num_games": p["num_games"]},
+    }
+    with open(path, "w") as f:
+        json.dump(out, f, indent=4)
+    return path

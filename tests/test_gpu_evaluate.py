@@ -1,0 +1,76 @@
+"""f1: the batched evaluation driver -- games played to completion on the GPU -- against the
+oracle playing the same games one by one with the same draw schedule (exact), and against the reference's
+published quality numbers (report.md) statistically."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)
+
+
+@pytest.fixture(scope="module")
+def g2048():
+    import __graft_entry__ as ge
+    return ge.import_package()
+
+
+def oracle_game(O, seed, gid, width, depth, max_moves):
+    k0, k1 = O.rng_keys(seed, O.DOM_RESET, 0)
+    b = O.env_reset(O.rng_draw(k0, k1, gid, 0), O.rng_draw(k0, k1, gid, 1))
+    score, moves, valid_n, invalid_n = 0, 0, 0, 0
+    ms = {m: None for m in MILESTONES}
+    done = False
+    while not done and moves < max_moves:
+        a = O.beam_get_action(b, -1, width, depth, seed=seed, step_index=moves, game_id=gid)["action"]
+        s0, s1 = O.rng_keys(seed, O.DOM_STEP, moves)
+        b, score, r, done, v, hi = O.env_step(b, score, a, O.rng_draw(s0, s1, gid, 0))
+        for m in MILESTONES:
+            if b.max() >= m and ms[m] is None:
+                ms[m] = moves
+        valid_n += int(v); invalid_n += int(not v)
+        moves += 1
+    return dict(score=score, moves=moves, valid=valid_n, invalid=invalid_n, board=b.reshape(4, 4), ms=ms)
+
+
+def test_evaluation_driver_exact_vs_oracle(g2048, oracle, tmp_path):
+    n, w, d, cap, seed = 48, 3, 4, 300, 0xBEEF
+    res = g2048.evaluate_beam_search(n, w, d, seed=seed, max_moves=cap, game_id_base=500, check_every=16)
+    for g in range(n):
+        ref = oracle_game(oracle, seed, 500 + g, w, d, cap)
+        assert res["scores"][g] == ref["score"] and res["moves"][g] == ref["moves"], g
+        assert res["valid_moves"][g] == ref["valid"] and res["invalid_moves"][g] == ref["invalid"], g
+        assert np.array_equal(res["final_boards"][g], ref["board"]), g
+        assert res["highest_tiles"][g] == ref["board"].max()
+    assert res["best_games"] == sorted(range(n), key=lambda i: res["scores"][i], reverse=True)[:5]
+    assert res["best_score"] == max(res["scores"]) and res["best_game_idx"] == res["best_games"][0]
+    from g2048.evaluate import save_overall_results
+    p = save_overall_results(res, str(tmp_path / "overall_results.json"))
+    js = json.load(open(p))
+    assert set(js) == {"scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games",
+                       "parameters"}
+    assert js["parameters"] == {"beam_width": w, "search_depth": d, "num_games": n}
+    assert set(js["milestones"]) == {str(m) for m in MILESTONES}
+
+
+def test_milestones_exact(g2048, oracle):
+    n, w, d, cap, seed = 12, 4, 6, 400, 77
+    res = g2048.evaluate_beam_search(n, w, d, seed=seed, max_moves=cap, check_every=8)
+    refs = [oracle_game(oracle, seed, g, w, d, cap) for g in range(n)]
+    for m in MILESTONES:
+        assert res["milestones"][m] == [r["ms"][m] for r in refs if r["ms"][m] is not None], m
+
+
+def test_quality_matches_reference_report(g2048):
+    """report.md (reference, beam w=20 d=30, 100 games): 35% of games reach >= 2048, average score 18,945.6,
+    average highest tile 1,315.8, ~4% hit the 5000-move cap. 1024 games here; the bands are +-4 sigma of a
+    100-game sample around the published values."""
+    res = g2048.evaluate_beam_search(1024, 20, 30, seed=2025, max_moves=5000)
+    s = res["summary"]
+    print("quality:", json.dumps({k: v for k, v in s.items() if k != "tile_distribution_pct"}), s["tile_distribution_pct"])
+    assert 0.15 < s["rate_2048_or_more"] < 0.55
+    assert 12000 < s["average_score"] < 26000
+    assert 900 < s["average_highest_tile"] < 1800
+    assert s["highest_tile"] >= 2048
