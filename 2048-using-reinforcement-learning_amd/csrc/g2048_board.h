@@ -520,6 +520,36 @@ G2048_HD double eval_ppo_heuristic(const Board &b)
     return score;
 }
 
+// sum of the four largest codes = sum over thresholds t >= 1 of min(4, #cells with code >= t).
+// Cell c contributes the unary mask (1 << c) - 1 (bit t-1 set <=> t <= c); the 16 masks are added into a
+// bit-sliced counter (ones / twos / saturating fours), so every threshold is counted at once.
+G2048_HD uint32_t top4_code_sum(const Board &b)
+{
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t x = (1u << ((b.w[r] >> (8 * k)) & 0xffu)) - 1u;
+            const uint32_t carry0 = c0 & x;
+            c0 ^= x;
+            c2 |= c1 & carry0;
+            c1 ^= carry0;
+        }
+    }
+    return 4u * popc(c2) + 2u * popc(c1 & ~c2) + popc(c0 & ~c2);
+}
+
+// The two pure per-transition shaping terms of PPOAgent.remember (agents/ppo_agent.py:253-266), added to
+// reward_in in the reference's order: + 0.1 * sum(log2 of the top-4 tiles) then + 0.3 * evaluate_heuristic.
+G2048_HD double eval_ppo_shaping(const Board &b, double reward_in)
+{
+    double reward = reward_in;
+    reward += 0.1 * (double)top4_code_sum(b);
+    reward += 0.3 * eval_ppo_heuristic(b);
+    return reward;
+}
+
 G2048_HD double eval_monotonicity(const Board &b, int kind /*0 ++,1 +-,2 -+,3 --*/)
 {
     const MonoCounts m = mono_counts(b);

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ 
     if (KIND == G2048_EVAL_FAST) v = eval_fast(b);
     else if (KIND == G2048_EVAL_FULL) v = eval_full(b, phase ? (uint32_t)phase[i] : phase_of(max_code(b), 512u, 1024u));
     else if (KIND == G2048_EVAL_PPO_HEURISTIC) v = eval_ppo_heuristic(b);
+    else if (KIND == G2048_EVAL_PPO_SHAPING) v = eval_ppo_shaping(b, 0.0);
     else v = eval_monotonicity(b, KIND - G2048_EVAL_MONO_PP);
     out[i] = v;
 }
@@ -334,6 +335,7 @@ int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, doubl
         G2048_EVAL_CASE(G2048_EVAL_MONO_PM)
         G2048_EVAL_CASE(G2048_EVAL_MONO_MP)
         G2048_EVAL_CASE(G2048_EVAL_MONO_MM)
+        G2048_EVAL_CASE(G2048_EVAL_PPO_SHAPING)
 #undef G2048_EVAL_CASE
         default: return fail(G2048_ERR_ARG, "g2048_eval: unknown kind %d", kind);
     }

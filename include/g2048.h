@@ -67,7 +67,9 @@ enum {
     G2048_EVAL_MONO_PP = 3,    /* PPOAgent.monotonicity(board, +1, +1)  ppo_agent.py:300-333 */
     G2048_EVAL_MONO_PM = 4,    /*                        (+1, -1) */
     G2048_EVAL_MONO_MP = 5,    /*                        (-1, +1) */
-    G2048_EVAL_MONO_MM = 6     /*                        (-1, -1) */
+    G2048_EVAL_MONO_MM = 6,    /*                        (-1, -1) */
+    G2048_EVAL_PPO_SHAPING = 7 /* the pure per-transition terms of PPOAgent.remember, ppo_agent.py:253-266:
+                                  0.1 * sum(log2(top-4 tiles)) + 0.3 * evaluate_heuristic (stateful terms excluded) */
 };
 
 /* opts of g2048_beam_get_action */

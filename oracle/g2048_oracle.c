@@ -516,6 +516,27 @@ double g2048o_ppo_heuristic(const int32_t b[16])
     return score;
 }
 
+/* agents/ppo_agent.py:253-266 (remember): the two PURE per-transition shaping terms, in the order the
+ * reference adds them to the reward (the stateful terms in between -- highest_tile_seen :241-246,
+ * regression :249-251 (unreachable), novelty :259-262 -- contribute 0 here):
+ *   reward += 0.1 * sum(log2(t) for t in sorted(next_state)[-4:] if t > 0)      :254-256
+ *   reward += 0.3 * evaluate_heuristic(next_state)                               :265-266          */
+double g2048o_ppo_shaping(const int32_t b[16], double reward_in)
+{
+    int32_t s[16]; memcpy(s, b, sizeof s);
+    for (int i = 1; i < 16; ++i) {                      /* np.sort ascending */
+        int32_t t = s[i]; int j = i - 1;
+        while (j >= 0 && s[j] > t) { s[j + 1] = s[j]; --j; }
+        s[j + 1] = t;
+    }
+    double sum = 0.0;
+    for (int i = 12; i < 16; ++i) if (s[i] > 0) sum += log2((double)s[i]);
+    double reward = reward_in;
+    reward += 0.1 * sum;
+    reward += 0.3 * g2048o_ppo_heuristic(b);
+    return reward;
+}
+
 /* ------------------------------------------------------ batched forms ---- */
 void g2048o_synth_boards(uint8_t *codes, uint64_t seed, uint64_t id_base, size_t n,
                          uint32_t p_empty_u16, uint32_t max_code)
@@ -608,7 +629,7 @@ void g2048o_valid_moves_batch(const uint8_t *boards, uint8_t *mask4, size_t n, i
 }
 
 /* kind: 0 fast, 1 full (phase[i] in 0..2), 2 ppo heuristic, 3..6 monotonicity
- * (+,+) (+,-) (-,+) (-,-).                                                  */
+ * (+,+) (+,-) (-,+) (-,-), 7 pure PPO shaping terms (reward_in = 0).          */
 void g2048o_eval_batch(const uint8_t *boards, int kind, const uint8_t *phase, double *out, size_t n)
 {
 #pragma omp parallel for schedule(static)
@@ -623,7 +644,8 @@ void g2048o_eval_batch(const uint8_t *boards, int kind, const uint8_t *phase, do
         case 3: v = g2048o_monotonicity(b, 1, 1); break;
         case 4: v = g2048o_monotonicity(b, 1, -1); break;
         case 5: v = g2048o_monotonicity(b, -1, 1); break;
-        default: v = g2048o_monotonicity(b, -1, -1); break;
+        case 6: v = g2048o_monotonicity(b, -1, -1); break;
+        default: v = g2048o_ppo_shaping(b, 0.0); break;
         }
         out[i] = v;
     }

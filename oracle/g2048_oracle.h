@@ -73,6 +73,7 @@ int    g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
 void   g2048o_normalize_state(const int32_t b[16], float out[16]);               /* :184-195 */
 double g2048o_monotonicity(const int32_t b[16], int row_dir, int col_dir);       /* :300-333 */
 double g2048o_ppo_heuristic(const int32_t b[16]);                                /* :271-298 */
+double g2048o_ppo_shaping(const int32_t b[16], double reward_in);                /* :253-266, pure terms */
 
 /* ---- batched forms over the packed layout (full-size checks, cpu_baseline) ---- */
 void g2048o_synth_boards(uint8_t *codes, uint64_t seed, uint64_t id_base, size_t n,

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libg2048_oracle.so")
 
 DOM_STEP, DOM_RESET, DOM_BEAM, DOM_SYNTH_BOARD, DOM_SYNTH_ACTION, DOM_EPISODE = 1, 2, 3, 4, 5, 6
-EVAL_FAST, EVAL_FULL, EVAL_PPO, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM = range(7)
+EVAL_FAST, EVAL_FULL, EVAL_PPO, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING = range(8)
 
 
 def build(force=False):
@@ -64,6 +64,7 @@ def lib():
             "g2048o_normalize_state": (None, [i32p, f32p]),
             "g2048o_monotonicity": (C.c_double, [i32p, C.c_int, C.c_int]),
             "g2048o_ppo_heuristic": (C.c_double, [i32p]),
+            "g2048o_ppo_shaping": (C.c_double, [i32p, C.c_double]),
             "g2048o_synth_boards": (None, [u8p, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32]),
             "g2048o_synth_actions": (None, [u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
             "g2048o_step_batch": (None, [u8p, u8p, u8p, u32p, f64p, u8p, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -174,6 +175,10 @@ def full_eval(board, phase):
 
 def ppo_heuristic(board):
     return lib().g2048o_ppo_heuristic(_p(_i32(board), C.c_int32))
+
+
+def ppo_shaping(board, reward_in=0.0):
+    return lib().g2048o_ppo_shaping(_p(_i32(board), C.c_int32), float(reward_in))
 
 
 def monotonicity(board, row_dir, col_dir):

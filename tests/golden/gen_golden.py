@@ -282,6 +282,7 @@ def gen_eval_scores(pool):
     heur = np.zeros(n, np.float64)
     mono = np.zeros((n, 4), np.float64)
     norm = np.zeros((n, 16), np.float32)
+    shaping = np.zeros(n, np.float64)
     phase_of = np.zeros(n, np.uint8)
     for i in range(n):
         t = tiles_of(pool[i])
@@ -293,11 +294,20 @@ def gen_eval_scores(pool):
         heur[i] = ppo.evaluate_heuristic(t.copy())
         for k, (rd, cd) in enumerate(((1, 1), (1, -1), (-1, 1), (-1, -1))):
             mono[i, k] = ppo.monotonicity(g.copy(), rd, cd)
+        # PPOAgent.remember (ppo_agent.py:234-269) with its stateful terms neutralised: no new-highest-tile
+        # bonus (highest_tile_seen huge), no novelty (hash pre-seeded), no regression (state == next_state);
+        # what is stored is 0 + 0.1*sum(log2 top-4) + 0.3*evaluate_heuristic(next_state)
+        ppo.highest_tile_seen = 1 << 30
+        ppo.seen_states.add(hash(t.tobytes()))
+        with contextlib.redirect_stdout(io.StringIO()):
+            ppo.remember(t.copy(), 0, 0.0, 0.0, t.copy(), False)
+        shaping[i] = float(ppo.memory.buffer[-1][3])
+        ppo.memory.clear()
         ns = ppo.normalize_state(t.copy())
         assert ns.dtype == np.float32
         norm[i] = ns
     np.savez_compressed(os.path.join(HERE, "eval_scores.npz"), board=pool, fast=fast, full=full, phase=phase_of,
-                        ppo_heuristic=heur, monotonicity=mono, normalize=norm)
+                        ppo_heuristic=heur, monotonicity=mono, normalize=norm, ppo_shaping=shaping)
     print("eval_scores", n)
 
 

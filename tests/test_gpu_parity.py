@@ -134,6 +134,7 @@ def test_eval_kernels(ops, oracle):
     assert np.array_equal(host(ops.evaluate(b, L.EVAL_PPO_HEURISTIC)), g["ppo_heuristic"])
     for k in range(4):
         assert np.array_equal(host(ops.evaluate(b, L.EVAL_MONO_PP + k)), g["monotonicity"][:, k])
+    assert np.array_equal(host(ops.evaluate(b, L.EVAL_PPO_SHAPING)), g["ppo_shaping"])
     assert np.array_equal(host(ops.obs(b)).view(np.uint32), g["normalize"].view(np.uint32))   # f32 bits
     big = ops.synth_boards(200000, seed=13, p_empty=0.2, max_code=15, device=DEV)
     hb = host(big)
@@ -141,6 +142,7 @@ def test_eval_kernels(ops, oracle):
     ph = (torch.arange(200000, device=DEV) % 3).to(torch.uint8)
     assert np.array_equal(host(ops.evaluate(big, L.EVAL_FULL, ph)), oracle.eval_batch(hb, oracle.EVAL_FULL, host(ph)))
     assert np.array_equal(host(ops.evaluate(big, L.EVAL_PPO_HEURISTIC)), oracle.eval_batch(hb, oracle.EVAL_PPO))
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_PPO_SHAPING)), oracle.eval_batch(hb, oracle.EVAL_PPO_SHAPING))
     assert np.array_equal(host(ops.obs(big)), oracle.obs_batch(hb))
 
 

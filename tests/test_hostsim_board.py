@@ -171,7 +171,9 @@ def test_eval_vs_golden_and_oracle(hs, oracle):
     assert np.array_equal(ev(b, 2), g["ppo_heuristic"])
     for k in range(4):
         assert np.array_equal(ev(b, 3 + k), g["monotonicity"][:, k])
+    assert np.array_equal(ev(b, 7), g["ppo_shaping"])
     rb = random_boards(60000, 11)
+    assert np.array_equal(ev(rb, 7), oracle.eval_batch(rb, oracle.EVAL_PPO_SHAPING))
     assert np.array_equal(ev(rb, 0), oracle.eval_batch(rb, oracle.EVAL_FAST))
     for ph in range(3):
         pa = np.full(rb.shape[0], ph, np.uint8)
