@@ -7,10 +7,13 @@
 //   * the draw index: the reference consumes its RNG sequentially in generation order
 //     (parent rank, then action); a child's position in that sequence is a ballot prefix count,
 //     so the j-th generated child of a decision always gets draw j, exactly as the Python loop does;
-//   * the top-k compaction: each candidate counts the candidates that sort before it
-//     (score descending, generation order ascending = Python's stable sorted(reverse=True)) with
-//     broadcast LDS reads of the score array, and the first `width` write themselves back to the
-//     beam at their rank.
+//   * the compaction of valid children: a move is tried for every (parent, action) slot, the children
+//     that changed the board are packed into LDS at their ballot-prefix index, and only those get the
+//     spawn and the heuristic -- usually one 64-lane round instead of two;
+//   * the top-k: each candidate counts the candidates that sort before it (score descending,
+//     generation order ascending = Python's stable sorted(reverse=True)) with broadcast LDS reads of
+//     the key array, and the first `width` write themselves back to the beam at their rank. On
+//     _fast_evaluate levels the score is a small integer, so (score, order) is one unique u32 key.
 // Scores are f64 in the reference's operation order (bit-exact with the oracle); no MFMA, no global
 // memory traffic inside the search (root in, action out).
 #include <hip/hip_runtime.h>
@@ -38,9 +41,11 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                                                  uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
                                                  uint64_t id_base, bool fixed_down)
 {
-    __shared__ uint4 s_board[kMaxWidth];
-    __shared__ uint32_t s_root[kMaxWidth];
-    __shared__ __align__(16) double s_score[64 * PASSES];
+    __shared__ uint4 s_board[kMaxWidth];                        // the beam, rank order
+    __shared__ uint32_t s_root[kMaxWidth];                      // root action of each beam entry
+    __shared__ uint4 s_cboard[64 * PASSES];                     // moved (pre-spawn) boards of the VALID children,
+    __shared__ uint32_t s_croot[64 * PASSES];                   //   compacted in generation order, + their root action
+    __shared__ __align__(16) double s_score[64 * PASSES + 2];   // f64 scores (levels 1..3) or, reinterpreted, u32 keys
 
     const uint32_t lane = threadIdx.x;
     const size_t g = blockIdx.x;
@@ -73,43 +78,35 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     for (int level = 0; level == 0 || level < actual_depth; ++level) {
         const int nslots = level == 0 ? 4 : 4 * nb;
         const bool fast = level == 0 || level > 3;             // :122, :139
-        Board child[PASSES];
-        double score[PASSES];
-        bool ok[PASSES];
-        uint32_t ract[PASSES];
+        // ---- stage A: one agent move per (parent, action) slot; valid children are compacted into LDS in
+        // generation order (parent rank, then action), which is also the order the reference draws in.
         uint32_t total_valid = 0;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int slot = p * 64 + (int)lane;
-            bool enabled = slot < nslots;
-            const uint32_t a = (uint32_t)slot & 3u;
-            Board P = root;
-            uint32_t ra = a;
-            if (level == 0) {
-                enabled = enabled && ((mask >> a) & 1u);
-            } else if (enabled) {
-                const uint4 pv = s_board[slot >> 2];
-                P = Board{{pv.x, pv.y, pv.z, pv.w}};
-                ra = s_root[slot >> 2];
+            if (p * 64 < nslots) {                                               // wave-uniform
+                const int slot = p * 64 + (int)lane;
+                bool enabled = slot < nslots;
+                const uint32_t a = (uint32_t)slot & 3u;
+                Board P = root;
+                uint32_t ra = a;
+                if (level == 0) {
+                    enabled = enabled && ((mask >> a) & 1u);
+                } else if (enabled) {
+                    const uint4 pv = s_board[slot >> 2];
+                    P = Board{{pv.x, pv.y, pv.z, pv.w}};
+                    ra = s_root[slot >> 2];
+                }
+                uint32_t gain;
+                const Board c = move_agent(P, a, gain, fixed_down);              // :115 / :152
+                const bool v = enabled && !same(c, P);
+                const unsigned long long bv = __ballot(v);
+                const uint32_t ci = total_valid + prefix_count(bv);
+                total_valid += (uint32_t)__popcll(bv);
+                if (v) {
+                    s_cboard[ci] = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
+                    s_croot[ci] = ra;
+                }
             }
-            uint32_t gain;
-            Board c = move_agent(P, a, gain, fixed_down);                       // :115 / :152
-            const bool v = enabled && !same(c, P);
-            const bool consume = v && count_empty(c) != 0u;                      // :262-263
-            const unsigned long long bc = __ballot(consume);
-            const uint32_t j = draws + prefix_count(bc);                         // generation order
-            draws += (uint32_t)__popcll(bc);
-            {
-                Board s = c;
-                spawn(s, rng_draw(k0, k1, gid, j));                              // :118 / :155
-                c.w[0] = consume ? s.w[0] : c.w[0]; c.w[1] = consume ? s.w[1] : c.w[1];
-                c.w[2] = consume ? s.w[2] : c.w[2]; c.w[3] = consume ? s.w[3] : c.w[3];
-            }
-            const double sc = fast ? eval_fast(c) : eval_full(c, phase);        // :122 / :158-161
-            const unsigned long long bv = __ballot(v);
-            total_valid += (uint32_t)__popcll(bv);
-            s_score[slot] = v ? sc : -INFINITY;
-            child[p] = c; score[p] = sc; ok[p] = v; ract[p] = ra;
         }
         expanded += total_valid;
         if (total_valid == 0u) {
@@ -127,24 +124,76 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
             break;                                                              // :170-171 keep the previous beam
         }
         __syncthreads();
-        // stable descending rank of every valid candidate (:131, :174)
+        // ---- stage B: spawn + score of the compacted children (one per lane; a second round only when
+        // more than 64 children are valid)
+        Board child[PASSES];
+        double score[PASSES];
+        uint32_t ikey[PASSES];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            score[p] = 0.0; ikey[p] = 0u; child[p] = root;
+            if ((uint32_t)(p * 64) < total_valid) {                              // wave-uniform
+                const uint32_t ci = (uint32_t)(p * 64) + lane;
+                const bool live = ci < total_valid;
+                const uint4 cv = s_cboard[live ? ci : 0u];
+                Board c = {{cv.x, cv.y, cv.z, cv.w}};
+                const bool consume = live && count_empty(c) != 0u;               // :262-263
+                const unsigned long long bc = __ballot(consume);
+                const uint32_t j = draws + prefix_count(bc);
+                draws += (uint32_t)__popcll(bc);
+                {
+                    Board s = c;
+                    spawn(s, rng_draw(k0, k1, gid, j));                          // :118 / :155
+                    c.w[0] = consume ? s.w[0] : c.w[0]; c.w[1] = consume ? s.w[1] : c.w[1];
+                    c.w[2] = consume ? s.w[2] : c.w[2]; c.w[3] = consume ? s.w[3] : c.w[3];
+                }
+                // :122 / :158-161. _fast_evaluate is integer-valued (< 2^19), so on those levels the sort key
+                // (score desc, generation order asc) is the single unique integer score * 256 + (255 - index);
+                // the f64 path is only needed for _evaluate_state (levels 1..3).
+                if (fast) {
+                    ikey[p] = live ? (eval_fast_u32(c) << 8) + (255u - ci) : 0u;
+                    reinterpret_cast<uint32_t *>(s_score)[ci] = ikey[p];         // ci < 64 * PASSES always
+                } else {
+                    score[p] = eval_full(c, phase);
+                    s_score[ci] = live ? score[p] : -INFINITY;
+                }
+                child[p] = c;
+            }
+        }
+        __syncthreads();
+        // ---- stable descending rank (:131, :174) among the valid children
         uint32_t rank[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) rank[p] = 0u;
-        for (int j = 0; j < nslots; j += 2) {
-            const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
+        const uint32_t nround = (total_valid + 63u) & ~63u;                       // entries beyond total_valid hold 0 / -inf
+        if (fast) {
+            const uint4 *keys = reinterpret_cast<const uint4 *>(s_score);
+            for (uint32_t j = 0; j < total_valid; j += 4) {
+                const uint4 kj = keys[j >> 2];
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int slot = p * 64 + (int)lane;
-                rank[p] += (sj.x > score[p] || (sj.x == score[p] && j < slot)) ? 1u : 0u;
-                rank[p] += (sj.y > score[p] || (sj.y == score[p] && j + 1 < slot)) ? 1u : 0u;
+                for (int p = 0; p < PASSES; ++p) {
+                    rank[p] += (kj.x > ikey[p] ? 1u : 0u) + (kj.y > ikey[p] ? 1u : 0u) +
+                               (kj.z > ikey[p] ? 1u : 0u) + (kj.w > ikey[p] ? 1u : 0u);
+                }
+            }
+        } else {
+            for (uint32_t j = 0; j < total_valid; j += 2) {
+                const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const uint32_t ci = (uint32_t)(p * 64) + lane;
+                    rank[p] += (sj.x > score[p] || (sj.x == score[p] && j < ci)) ? 1u : 0u;
+                    rank[p] += (sj.y > score[p] || (sj.y == score[p] && j + 1 < ci)) ? 1u : 0u;
+                }
             }
         }
+        (void)nround;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            if (ok[p] && rank[p] < (uint32_t)width) {                            // :132 / :175
+            const uint32_t ci = (uint32_t)(p * 64) + lane;
+            if (ci < total_valid && rank[p] < (uint32_t)width) {                  // :132 / :175
                 s_board[rank[p]] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
-                s_root[rank[p]] = ract[p];
+                s_root[rank[p]] = s_croot[ci];
             }
         }
         nb = (int)min(total_valid, (uint32_t)width);

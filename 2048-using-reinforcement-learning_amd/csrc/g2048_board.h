@@ -420,16 +420,14 @@ G2048_HD uint32_t max_corner_code(const Board &b)
 
 // BeamSearchAgent._fast_evaluate (agents/beam_search_agent.py:280-314):
 // empty*10 + log2(max)*2 + max non-empty corner*2 + 2*(#adjacent equal pairs). Integer-valued.
-G2048_HD double eval_fast(const Board &b)
+// Every term is a small integer (< 2^19 in total), so the value is exact in any of u32 / f32 / f64.
+G2048_HD uint32_t eval_fast_u32(const Board &b)
 {
-    const uint32_t e = count_empty(b);
-    const uint32_t mc = max_code(b);
     const uint32_t cc = max_corner_code(b);
-    const uint32_t corner = cc ? (2u << cc) : 0u;
-    const double empty_score = (double)e * 10.0;
-    const double max_score = (double)mc * 2.0;
-    return ((empty_score + max_score) + (double)corner) + (double)(pair_count(b) * 2u);
+    return count_empty(b) * 10u + max_code(b) * 2u + (cc ? (2u << cc) : 0u) + pair_count(b) * 2u;
 }
+
+G2048_HD double eval_fast(const Board &b) { return (double)eval_fast_u32(b); }
 
 // sum of codes over adjacent equal non-zero pairs (_calculate_merge_potential, :387-403)
 G2048_HD uint32_t merge_potential(const Board &b)
