@@ -128,8 +128,8 @@ G2048_HD Board rot180(const Board &b)
 // agents/beam_search_agent.py:213-242): drop zeros, scan toward the far end,
 // equal neighbours merge once into code+1 (score += 2^(code+1)), pad with zeros.
 // Here: L[k] holds position k of four independent lines (one per byte lane),
-// sliding toward k = 0. Returns the score gained by all four lines.
-G2048_HD uint32_t slide_lines(uint32_t L[4])
+// sliding toward k = 0. Returns the score gained by all four lines; merges = number of merge events.
+G2048_HD uint32_t slide_lines(uint32_t L[4], uint32_t &merges)
 {
     // compaction: three stages, stage k closes a hole at position k
     {
@@ -158,26 +158,24 @@ G2048_HD uint32_t slide_lines(uint32_t L[4])
     const uint32_t o2 = pick(pick(0u, D, s23), pick(D, Cp, s12), s01);
     const uint32_t o3 = pick(0u, D, selof(m01 | m12 | m23));
     L[0] = o0; L[1] = o1; L[2] = o2; L[3] = o3;
-    // score: merged tiles sit in o0 (m01), o1 (m01&m23 | m12), o2 (m23 & ~m01)
+    // score: merged tiles sit in o0 (m01) and in o1 (m01&m23 | m12) or o2 (m23 & ~m01); the last two
+    // never share a byte lane (m12 excludes m23, m01&m23 excludes ~m01), so they fold into one word.
     const uint32_t g1 = (m01 & m23) | m12, g2 = m23 & ~m01;
-    const uint32_t any = m01 | g1 | g2;
+    merges = popc(m01) + popc(g1 | g2);             // every merge frees exactly one cell
     uint32_t gain = 0;
-    if (any) {      // wave-level skip when no lane merged anything (cheap, common late in dense boards)
-        const uint32_t G0 = pick(o0, 0u, s01), G1 = pick(o1, 0u, selof(g1)), G2 = pick(o2, 0u, selof(g2));
+    if (merges) {
+        const uint32_t G0 = pick(o0, 0u, s01), G12 = pick(o1, 0u, selof(g1)) | pick(o2, 0u, selof(g2));
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc += (1u << ((G0 >> (8 * k)) & 0xffu)) + (1u << ((G1 >> (8 * k)) & 0xffu)) + (1u << ((G2 >> (8 * k)) & 0xffu));
-        }
-        // every non-merged byte contributed 1<<0
-        gain = acc - (12u - popc(m01) - popc(g1) - popc(g2));
+        for (int k = 0; k < 4; ++k) acc += (1u << ((G0 >> (8 * k)) & 0xffu)) + (1u << ((G12 >> (8 * k)) & 0xffu));
+        gain = acc - (8u - merges);                 // every non-merged byte contributed 1 << 0
     }
     return gain;
 }
 
 // One move on the whole board. action: 0 LEFT, 1 UP, 2 RIGHT, 3 DOWN
 // (environment/game_2048.py:11-16). Env semantics (:97-114).
-G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
+G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain, uint32_t &merges)
 {
     const bool horiz = (action & 1u) == 0u;
     const bool rev = (action & 2u) != 0u;
@@ -188,7 +186,7 @@ G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
         const uint32_t x2 = horiz ? t.w[2] : b.w[2], x3 = horiz ? t.w[3] : b.w[3];
         L[0] = rev ? x3 : x0; L[1] = rev ? x2 : x1; L[2] = rev ? x1 : x2; L[3] = rev ? x0 : x3;
     }
-    gain = slide_lines(L);
+    gain = slide_lines(L, merges);
     Board v;
     v.w[0] = rev ? L[3] : L[0]; v.w[1] = rev ? L[2] : L[1]; v.w[2] = rev ? L[1] : L[2]; v.w[3] = rev ? L[0] : L[3];
     const Board vt = transpose(v);
@@ -196,6 +194,12 @@ G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
     o.w[0] = horiz ? vt.w[0] : v.w[0]; o.w[1] = horiz ? vt.w[1] : v.w[1];
     o.w[2] = horiz ? vt.w[2] : v.w[2]; o.w[3] = horiz ? vt.w[3] : v.w[3];
     return o;
+}
+
+G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
+{
+    uint32_t merges;
+    return move_env(b, action, gain, merges);
 }
 
 // BeamSearchAgent._make_move (agents/beam_search_agent.py:194-258): LEFT/UP/RIGHT
@@ -305,7 +309,7 @@ struct TileStats {
     uint32_t orbits;     // OR of (1 << code) over all cells (bit 0 set iff any empty)
 };
 
-G2048_HD TileStats tile_stats(const Board &b)
+G2048_HD TileStats tile_stats(const Board &b, uint32_t n_empty)
 {
     uint32_t rs[4], outer = 0, orb = 0;
 #pragma unroll
@@ -319,7 +323,7 @@ G2048_HD TileStats tile_stats(const Board &b)
     }
     // empty cells contributed 1 each: subtract their counts
     const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
-    const uint32_t zall = popc(z0) + popc(z1) + popc(z2) + popc(z3);
+    const uint32_t zall = n_empty;
     const uint32_t zcols = popc((z0 | (z1 >> 1) | (z2 >> 2) | (z3 >> 3)) & 0xf00000f0u);  // col 0 and col 3 flags of 4 rows
     TileStats s;
     s.total = rs[0] + rs[1] + rs[2] + rs[3] - zall;
@@ -328,9 +332,11 @@ G2048_HD TileStats tile_stats(const Board &b)
     return s;
 }
 
+G2048_HD TileStats tile_stats(const Board &b) { return tile_stats(b, count_empty(b)); }
+
 G2048_HD uint32_t max_code(const Board &b)
 {
-    const TileStats s = tile_stats(b);
+    const TileStats s = tile_stats(b, 0u);          // only .orbits is used
     return 31u - (uint32_t)__builtin_clz(s.orbits | 1u);
 }
 
@@ -383,17 +389,21 @@ struct StepOut { Board board; uint32_t gain; double reward; uint32_t flags; };
 G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
 {
     StepOut o;
-    Board cur = move_env(prev, action, o.gain);
+    uint32_t merges;
+    Board cur = move_env(prev, action, o.gain, merges);
     const bool valid = !same(cur, prev);
-    const uint32_t empty_before = count_empty(prev);
+    uint32_t empty_mid;                 // empties of the moved board, before the spawn
     {
         Board spawned = cur;
-        spawn(spawned, h);
+        empty_mid = spawn(spawned, h);
         cur.w[0] = valid ? spawned.w[0] : cur.w[0]; cur.w[1] = valid ? spawned.w[1] : cur.w[1];
         cur.w[2] = valid ? spawned.w[2] : cur.w[2]; cur.w[3] = valid ? spawned.w[3] : cur.w[3];
     }
-    const uint32_t empty_after = count_empty(cur);
-    const TileStats st = tile_stats(cur);
+    // a slide moves tiles and every merge frees one cell; a valid move then fills one (a valid move always
+    // leaves an empty cell: either a tile slid into a gap or a merge freed a cell)
+    const uint32_t empty_before = empty_mid - merges;
+    const uint32_t empty_after = empty_mid - (valid ? 1u : 0u);
+    const TileStats st = tile_stats(cur, empty_after);
     o.reward = reward_env(cur, st, o.gain, valid, empty_before, empty_after);
     const bool done = game_over_counted(cur, empty_after);
     const uint32_t maxcode = 31u - (uint32_t)__builtin_clz(st.orbits | 1u);

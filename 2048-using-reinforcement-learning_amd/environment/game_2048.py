@@ -30,10 +30,15 @@ class Game2048Env:
         L.lib()
         self.seed = random.getrandbits(63) if seed is None else int(seed)
         self._boards = torch.zeros((1, 16), dtype=torch.uint8, device=self.device)
-        self._scores = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._action = torch.zeros(1, dtype=torch.uint8, device=self.device)
-        self._reward = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self._flags = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        # one 80-byte device record receives everything a step produces, so a step costs ONE device->host
+        # copy: [0:64) tiles int32[16] | [64:68) score int32 | [68] flags | [72:80) reward float64
+        self._rec = torch.zeros(80, dtype=torch.uint8, device=self.device)
+        self._tiles = self._rec[0:64].view(torch.int32).view(1, 16)
+        self._scores = self._rec[64:68].view(torch.int32)
+        self._flags = self._rec[68:69]
+        self._reward = self._rec[72:80].view(torch.float64)
+        self._host = torch.zeros(80, dtype=torch.uint8).pin_memory()
         self._t = 0
         self._epoch = 0
         self.highest_tile = 0
@@ -60,8 +65,14 @@ class Game2048Env:
         self._scores.fill_(int(value))
 
     def _pull(self):
-        self._board_np = ops.unpack(self._boards).cpu().numpy().reshape(4, 4)
-        self._score = np.int32(self._scores.item())
+        """Refresh the host mirrors; returns (flags, reward) of the last step."""
+        ops.unpack(self._boards, out=self._tiles)
+        self._host.copy_(self._rec, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        h = self._host.numpy()
+        self._board_np = h[0:64].view(np.int32).reshape(4, 4).copy()
+        self._score = np.int32(h[64:68].view(np.int32)[0])
+        return int(h[68]), np.float64(h[72:80].view(np.float64)[0])
 
     # -- reference API ---------------------------------------------------------
     def reset(self):                                           # reference :29-48
@@ -85,9 +96,7 @@ class Game2048Env:
         ops.step(self._boards, self._action, self._scores, self.seed, self._t, 0, out=self._boards,
                  reward=self._reward, flags=self._flags, reward_f64=True)
         self._t += 1
-        flags = int(self._flags.item())
-        self._pull()
-        reward = np.float64(self._reward.item())
+        flags, reward = self._pull()
         self.game_over = bool(flags & L.FLAG_DONE)
         current_highest = np.max(self._board_np)
         if current_highest > self.highest_tile:

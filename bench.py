@@ -97,6 +97,8 @@ def main():
                     one_step(W + t)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
+        graph.replay()                  # untimed: the first replay pays the graph's one-time upload
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps -------------------------------------------------
     # wall clock between barrier + synchronize pairs (-> value), and a HIP event pair on the launch
@@ -214,14 +216,20 @@ def main():
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), bo) and np.array_equal(flags.cpu().numpy(), fo), "GPU != oracle"
         if not args.no_beam:
-            sub = 256
-            c0 = time.perf_counter()
-            oa, op, oe = O.beam_batch(roots[:sub].cpu().numpy(), BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10,
-                                      game_id_base=0)
+            hr = roots.cpu().numpy()
+            c0 = time.perf_counter(); cexp = 0; cdec = 0
+            while time.perf_counter() - c0 < args.cpu_seconds and cdec < 100:
+                oa, op, oe = O.beam_batch(hr, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec, game_id_base=0)
+                cexp += int(oe.sum()); cdec += 1
             csec = time.perf_counter() - c0
-            result["beam"]["cpu_baseline"] = {"value": float(oe.sum()) / csec, "unit": "expansions/s",
+            result["beam"]["cpu_baseline"] = {"value": cexp / csec, "unit": "expansions/s",
                                               "cores": O.num_threads(), "kind": "port",
-                                              "sample": "%d of the 4096 roots, one decision each (%.1f s)" % (sub, csec)}
+                                              "sample": "%d batch decisions over the same 4096 roots (%.1f s, OpenMP "
+                                                        "dynamic over games)" % (cdec, csec)}
+            a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
+                                          game_id_base=0, want_expanded=True)
+            assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(e.cpu().numpy().astype(np.uint32), oe), \
+                "GPU beam != oracle"
 
     if rank == 0:
         print(json.dumps(result))

@@ -230,3 +230,63 @@ def test_metrics_kernel(ops):
     assert m[0] == n and m[1] == int(sc.sum()) and m[2] == int(fl.sum())
     hist = np.bincount(host(b).max(axis=1), minlength=18)
     assert np.array_equal(m[4:22], hist)
+
+
+def test_empty_batches_are_noops(ops):
+    """n == 0 through every entry point: nothing launched, nothing raised."""
+    from g2048 import _lib as L
+    e = torch.empty((0, 16), dtype=torch.uint8, device=DEV)
+    z8 = torch.empty(0, dtype=torch.uint8, device=DEV)
+    z32 = torch.empty(0, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(e, z8, z32, seed=1, step_index=0)
+    assert out.shape == (0, 16) and rw.numel() == 0 and fl.numel() == 0
+    assert ops.valid_moves(e).numel() == 0 and ops.evaluate(e, L.EVAL_FAST).numel() == 0
+    assert ops.obs(e).shape == (0, 16) and ops.unpack(e).shape == (0, 16)
+    a, p = ops.beam_get_action(e, 20, 30)
+    assert a.numel() == 0 and p.numel() == 0
+    assert int(ops.metrics(e).sum()) == 0
+
+
+def test_config5_total_on_one_gpu_properties(ops):
+    """Config 5's global problem (8,388,608 boards) in one launch: size-independent properties, plus equality of
+    eight 1,048,576-board shard launches with the single launch (what the 8-GPU run computes)."""
+    n = 8 * (1 << 20)
+    b = ops.synth_boards(n, seed=0x2048, device=DEV)
+    a = ops.synth_actions(n, seed=0x2048, step_index=0, device=DEV)
+    sc = torch.zeros(n, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, seed=0x2048, step_index=0)
+    valid = (fl & 2).bool()
+    diff = ops.unpack(out).sum(dim=1) - ops.unpack(b).sum(dim=1)
+    assert bool(((diff == 2) | (diff == 4))[valid].all()) and bool((diff == 0)[~valid].all())
+    assert bool(((ops.valid_moves(out) == 0) == (fl & 1).bool()).all())
+    m = ops.metrics(out, sc, fl)
+    assert int(m[0]) == n and int(m[1]) == int(sc.sum(dtype=torch.int64)) and int(m[4:22].sum()) == n
+    shard = 1 << 20
+    for r in (0, 3, 7):
+        bs = ops.synth_boards(shard, seed=0x2048, id_base=r * shard, device=DEV)
+        as_ = ops.synth_actions(shard, seed=0x2048, step_index=0, id_base=r * shard, device=DEV)
+        scs = torch.zeros(shard, dtype=torch.int32, device=DEV)
+        o2, r2, f2 = ops.step(bs, as_, scs, seed=0x2048, step_index=0, id_base=r * shard)
+        sl = slice(r * shard, (r + 1) * shard)
+        assert bool((o2 == out[sl]).all()) and bool((r2 == rw[sl]).all()) and bool((f2 == fl[sl]).all())
+        assert bool((scs == sc[sl]).all())
+
+
+def test_drop_in_env_single_step_rate(ops):
+    """Config 1 plumbing: the look-alike Game2048Env (one board, n = 1 launches). Prints its step rate next to the
+    reference's ~2.3e3 steps/s; must at least be in that league."""
+    import time
+    from environment.game_2048 import Game2048Env
+    env = Game2048Env(seed=5)
+    env.reset()
+    for _ in range(20):
+        env.step(1)
+    t0 = time.perf_counter(); steps = 0
+    for t in range(400):
+        s, r, d, info = env.step(t & 3)
+        steps += 1
+        if d:
+            env.reset()
+    dt = time.perf_counter() - t0
+    print("drop-in Game2048Env: %.0f single-board steps/s (reference CPython env: ~2.3e3)" % (steps / dt))
+    assert steps / dt > 1000
