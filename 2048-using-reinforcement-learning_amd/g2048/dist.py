@@ -21,11 +21,18 @@ def init(backend=None, device=None):
     w, r, lr = world()
     if w > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("G2048_DIST_BACKEND") or backend      # rehearsal override (e.g. gloo on one GPU)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return w, r, lr
+
+
+def _staged(t):
+    """gloo has no device collectives for every op used here: when rehearsing on gloo with device tensors the
+    exchange is staged through the host (never taken on RCCL)."""
+    return dist.get_backend() == "gloo" and t.is_cuda
 
 
 def shard(n_global, rank, world_size):
@@ -45,6 +52,8 @@ def all_gather_scores(scores):
     all_gather_into_tensor; ragged shards fall back to all_gather of padded tensors."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return scores.clone()
+    if _staged(scores):
+        return all_gather_scores(scores.cpu()).to(scores.device)
     w = dist.get_world_size()
     n = torch.tensor([scores.numel()], dtype=torch.int64, device=scores.device)
     sizes = [torch.zeros_like(n) for _ in range(w)]
@@ -65,13 +74,18 @@ def all_gather_scores(scores):
 def reduce_metrics(metrics):
     """Sum of the per-shard metric vectors (g2048_metrics layout) over all ranks, in place."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
+        if _staged(metrics):
+            h = metrics.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            metrics.copy_(h)
+        else:
+            dist.all_reduce(metrics, op=dist.ReduceOp.SUM)
     return metrics
 
 
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

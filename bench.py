@@ -59,8 +59,10 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    local_dev = local_rank % ndev            # normally local_rank; a 2-rank rehearsal on one GPU shares cuda:0
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     ge.import_package()
     from g2048 import ops, _lib, dist as gdist
     gdist.init("nccl", dev)
