@@ -347,10 +347,9 @@ G2048_HD uint32_t max_code(const Board &b)
 // :200-203) -- with max(prev_board); the two are always equal inside step(), so
 // the branch is dead there and is not generated. `cur` is the post-spawn board.
 // Must be compiled with -ffp-contract=off (the 0.1 terms are mul THEN add).
-G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
-                           uint32_t empty_before, uint32_t empty_after)
+G2048_HD double reward_env_from(double r, const Board &cur, const TileStats &st, bool valid,
+                                uint32_t empty_before, uint32_t empty_after)
 {
-    double r = (double)gain / 4.0;
     if (!valid) r -= 2.0;
     r += (double)((int)empty_after - (int)empty_before) * 0.5;
     r += ((double)st.edge / (double)st.total) * 1.0;
@@ -369,6 +368,12 @@ G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain,
         r += (double)c * 0.1;
     }
     return r;
+}
+
+G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
+                           uint32_t empty_before, uint32_t empty_after)
+{
+    return reward_env_from((double)gain / 4.0, cur, st, valid, empty_before, empty_after);
 }
 
 // done <=> no direction changes the board (environment/game_2048.py:279-288): a full board
@@ -409,6 +414,61 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
     const uint32_t maxcode = 31u - (uint32_t)__builtin_clz(st.orbits | 1u);
     o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);
     o.board = cur;
+    return o;
+}
+
+// --------------------------------------------------------- simulate_move ------
+// The first `full` empty cells of m (row-major) get a 4 (code 2), the next one gets code `last` (0 = leave
+// it). Ranks of the empty cells come from a byte-wise inclusive prefix sum of the zero indicators.
+G2048_HD Board fill_empties(const Board &m, uint32_t full, uint32_t last)
+{
+    const uint32_t ones = 0x01010101u;
+    uint32_t z[4], p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { z[r] = zflag(m.w[r]); p[r] = (z[r] >> 7) * ones; }
+    const uint32_t o1 = p[0] >> 24, o2 = o1 + (p[1] >> 24), o3 = o2 + (p[2] >> 24);
+    const uint32_t fullb = full * ones, nextb = (full + 1u) * ones;
+    Board o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t rank = p[r] + (r == 0 ? 0u : r == 1 ? o1 : r == 2 ? o2 : o3) * ones;     // 1-based, <= 16
+        const uint32_t le = geflag(fullb, rank) & z[r];
+        const uint32_t eq = zflag(rank ^ nextb) & z[r];
+        o.w[r] = m.w[r] | (le >> 6) | ((eq >> 7) * last);
+    }
+    return o;
+}
+
+// Game2048Env.simulate_move (environment/game_2048.py:341-387), successor k of (state, action) as the reference
+// actually produces it: `empty` is listed once from the moved board M; successor k = 2*i + t sets empty[i] to
+// 2 (t = 0) or 4 (t = 1) ON TOP OF the previous successor (self.board = new_state.copy(), :378), so empty[0..i)
+// already hold 4; its reward is _calculate_reward(True, state, score) evaluated while self.board is still the
+// PREVIOUS successor (M for k = 0) and with the env's own highest_tile attribute (so the milestone branch
+// :229-241 is live here); done is is_game_over() of the successor itself.
+struct SimOut { Board board; double reward; bool done; };
+
+G2048_HD uint32_t simulate_count(const Board &state, uint32_t action, Board &moved, uint32_t &gain)
+{
+    moved = move_env(state, action, gain);
+    return same(moved, state) ? 0u : 2u * count_empty(moved);
+}
+
+G2048_HD SimOut simulate_successor(const Board &state, const Board &moved, uint32_t gain, uint32_t k, uint32_t highest_code)
+{
+    SimOut o;
+    o.board = fill_empties(moved, k >> 1, (k & 1u) ? 2u : 1u);
+    const Board seen = k == 0u ? moved : fill_empties(moved, (k - 1u) >> 1, ((k - 1u) & 1u) ? 2u : 1u);
+    double r = (double)gain / 4.0;
+    if (highest_code > max_code(state)) {          // :229-241; every term is exact at these magnitudes
+        r += 2.0 * (double)highest_code;
+        if (highest_code >= 8u) r += 50.0;
+        if (highest_code >= 9u) r += 100.0;
+        if (highest_code >= 10u) r += 200.0;
+        if (highest_code >= 11u) r += 500.0;
+    }
+    const uint32_t seen_empty = count_empty(seen);
+    o.reward = reward_env_from(r, seen, tile_stats(seen, seen_empty), true, count_empty(state), seen_empty);
+    o.done = game_over_counted(o.board, count_empty(o.board));
     return o;
 }
 

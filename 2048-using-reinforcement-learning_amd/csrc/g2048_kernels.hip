@@ -122,6 +122,31 @@ __global__ __launch_bounds__(kBlock) void valid_kernel(const uint4 *__restrict__
     mask_out[i] = (uint8_t)(AGENT ? valid_mask_agent(b, false) : valid_mask_env(b));
 }
 
+// ---------------------------------------------------------- simulate_move -----
+// 32 lanes per board (at most 15 empty cells x 2 tiles = 30 successors), lane k builds successor k.
+__global__ __launch_bounds__(kBlock) void simulate_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ actions,
+                                                         const uint8_t *__restrict__ highest_code, uint4 *__restrict__ succ,
+                                                         double *__restrict__ reward, uint8_t *__restrict__ done,
+                                                         uint8_t *__restrict__ count, size_t n)
+{
+    const size_t gidx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t b = gidx >> 5;
+    const uint32_t k = (uint32_t)gidx & 31u;
+    if (b >= n) return;
+    const Board state = load_board(boards, b);
+    Board moved;
+    uint32_t gain;
+    const uint32_t nsucc = simulate_count(state, actions[b] & 3u, moved, gain);
+    const uint32_t hc = highest_code ? (uint32_t)highest_code[b] : max_code(state);
+    SimOut o;
+    o.board = Board{{0u, 0u, 0u, 0u}}; o.reward = 0.0; o.done = false;
+    if (k < nsucc) o = simulate_successor(state, moved, gain, k, hc);
+    store_board(succ, gidx, o.board);
+    reward[gidx] = o.reward;
+    done[gidx] = o.done ? 1 : 0;
+    if (k == 0) count[b] = (uint8_t)nsucc;
+}
+
 // ------------------------------------------------------------------- eval -----
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ phase,
@@ -318,6 +343,20 @@ int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t
     if (opts == G2048_VALID_AGENT) hipLaunchKernelGGL(valid_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     else hipLaunchKernelGGL(valid_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     return check_launch("g2048_valid_moves");
+}
+
+int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null, void *succ_boards_out,
+                        double *reward_out, uint8_t *done_out, uint8_t *count_out, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !actions || !succ_boards_out || !reward_out || !done_out || !count_out)
+        return fail(G2048_ERR_ARG, "g2048_simulate_move: null pointer");
+    if (!aligned16(boards) || !aligned16(succ_boards_out) || (reinterpret_cast<uintptr_t>(reward_out) & 7u))
+        return fail(G2048_ERR_ARG, "g2048_simulate_move: misaligned array");
+    hipLaunchKernelGGL(simulate_kernel, dim3(blocks_for(n * 32)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(boards), actions, highest_code_or_null, static_cast<uint4 *>(succ_boards_out),
+                       reward_out, done_out, count_out, n);
+    return check_launch("g2048_simulate_move");
 }
 
 int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream)

@@ -107,6 +107,20 @@ class Game2048Env:
             "highest_tile": self.highest_tile,
         }
 
+    def simulate_move(self, state, action):                    # reference :341-387
+        """All (next_state, reward, done) successors of `action` on `state`, as the reference lists them
+        (it does not touch the env's own board or score)."""
+        tiles = torch.as_tensor(np.ascontiguousarray(state, dtype=np.int32).reshape(1, 16), device=self.device)
+        hi = int(self.highest_tile)
+        hc = torch.tensor([hi.bit_length() - 1 if hi > 0 else 0], dtype=torch.uint8, device=self.device)
+        act = torch.tensor([int(action) & 3], dtype=torch.uint8, device=self.device)
+        succ, reward, done, count = ops.simulate_move(ops.pack(tiles), act, hc)
+        k = int(count.item())
+        states = ops.unpack(succ[0, :k].contiguous()).cpu().numpy()
+        rewards = reward[0, :k].cpu().numpy()
+        dones = done[0, :k].cpu().numpy()
+        return [(states[i], np.float64(rewards[i]), bool(dones[i])) for i in range(k)]
+
     def is_game_over(self):                                    # reference :279-288
         return not any(self.get_valid_moves())
 

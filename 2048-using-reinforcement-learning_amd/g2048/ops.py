@@ -94,6 +94,29 @@ def obs(boards, out=None):
     return out
 
 
+def simulate_move(boards, actions, highest_code=None):
+    """Game2048Env.simulate_move for every (board, action) (environment/game_2048.py:341-387).
+    Returns (succ uint8 (n,32,16), reward float64 (n,32), done bool (n,32), count uint8 (n,)); only the first
+    count[i] slots of row i are successors, in the reference's order."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    n = boards.shape[0]
+    if actions.shape[0] != n:
+        raise ValueError("g2048: actions length must equal the number of boards")
+    if highest_code is not None:
+        L.require_device_tensor(highest_code, torch.uint8, None, "highest_code")
+    dev = boards.device
+    succ = torch.empty((n, 32, 16), dtype=torch.uint8, device=dev)
+    reward = torch.empty((n, 32), dtype=torch.float64, device=dev)
+    done = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    count = torch.empty(n, dtype=torch.uint8, device=dev)
+    L.check(L.lib().g2048_simulate_move(boards.data_ptr(), actions.data_ptr(),
+                                        highest_code.data_ptr() if highest_code is not None else None,
+                                        succ.data_ptr(), reward.data_ptr(), done.data_ptr(), count.data_ptr(), n,
+                                        L.stream_ptr(dev)))
+    return succ, reward, done.bool(), count
+
+
 def pack(tiles, out=None):
     """int32 (n,16) real tile values (the reference's state layout) -> packed codes."""
     L.require_device_tensor(tiles, torch.int32, (16,), "tiles")

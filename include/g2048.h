@@ -115,6 +115,16 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
                           uint32_t opts, void *stream);
 
+/* Game2048Env.simulate_move (environment/game_2048.py:341-387) for n (state, action) pairs: every successor the
+ * reference lists -- 2 per empty cell of the moved board, at most 30 -- in its order and with its behaviour (each
+ * successor is built on top of the previous one; its reward is computed on the previous successor's board and
+ * includes the milestone bonus against highest_code, the env's highest_tile attribute as a log2 code; NULL = the
+ * state's own max, as inside an episode). Outputs are 32 slots per state: succ_boards_out n*32 boards,
+ * reward_out n*32 f64, done_out n*32 bytes; count_out[i] = number of valid slots (0 when the move is invalid). */
+int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null,
+                        void *succ_boards_out, double *reward_out, uint8_t *done_out, uint8_t *count_out,
+                        size_t n, void *stream);
+
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
 int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream);

@@ -240,6 +240,40 @@ void g2048o_env_reset(int32_t b[16], uint32_t h0, uint32_t h1)
     g2048o_spawn(b, h1);
 }
 
+/* environment/game_2048.py:341-387 (simulate_move), restated with its actual behaviour:
+ *   - the move is executed on a copy of `state`; nothing is produced when the board does not change;
+ *   - `empty` is taken once from the moved board M (row-major); for every empty cell, tiles 2 then 4:
+ *       new_state = self.board.copy()   -- self.board is the PREVIOUS iteration's new_state (:371 after :378), so
+ *                                          tiles accumulate: earlier cells end up holding 4;
+ *       reward    = _calculate_reward(True, state, original_score) evaluated while self.board is still the
+ *                   previous iteration's board (M for the first) and self.highest_tile is the env's own attribute,
+ *                   so the milestone branch (:229-241) can fire here;
+ *       done      = is_game_over() on new_state.
+ * Returns the number of successors (0 or 2 * #empty(M)).                                                   */
+int g2048o_simulate_move(const int32_t state[16], int action, int32_t highest_tile,
+                         int32_t *succ /* [32][16] */, double *reward /* [32] */, uint8_t *done /* [32] */)
+{
+    int32_t board[16]; memcpy(board, state, sizeof board);
+    int32_t gain = 0;
+    g2048o_env_move(board, action, &gain);
+    if (memcmp(board, state, sizeof board) == 0) return 0;
+    int pos[16]; int ne = 0;
+    for (int i = 0; i < 16; ++i) if (board[i] == 0) pos[ne++] = i;
+    int k = 0;
+    for (int i = 0; i < ne; ++i) {
+        for (int t = 0; t < 2; ++t) {
+            int32_t ns[16]; memcpy(ns, board, sizeof ns);
+            ns[pos[i]] = t ? 4 : 2;
+            reward[k] = env_reward_full(state, board, gain, 1, highest_tile);
+            memcpy(board, ns, sizeof ns);
+            done[k] = (uint8_t)(g2048o_env_valid_mask(board) == 0);
+            memcpy(succ + 16 * k, ns, sizeof ns);
+            ++k;
+        }
+    }
+    return k;
+}
+
 /* ------------------------------------------------------ beam agent ------- */
 /* agents/beam_search_agent.py:194-258 (_make_move). Pre-transform for DOWN is
  * fliplr(board.T) (:210); post-transform is board.T then fliplr (:252-253),

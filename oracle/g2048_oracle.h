@@ -50,6 +50,8 @@ double g2048o_env_reward(const int32_t prev[16], const int32_t cur[16],
 int    g2048o_env_step(int32_t b[16], int32_t *score, int action, uint32_t h,
                        double *reward, int *done, int32_t *highest_tile);
 void   g2048o_env_reset(int32_t b[16], uint32_t h0, uint32_t h1);               /* :29-48 */
+int    g2048o_simulate_move(const int32_t state[16], int action, int32_t highest_tile,
+                            int32_t *succ, double *reward, uint8_t *done);          /* :341-387 */
 
 /* ---- beam agent (agents/beam_search_agent.py) ---- */
 void   g2048o_agent_move(const int32_t in[16], int action, int32_t out[16],

@@ -53,6 +53,7 @@ def lib():
             "g2048o_env_reward": (C.c_double, [i32p, i32p, C.c_int32, C.c_int]),
             "g2048o_env_step": (C.c_int, [i32p, i32p, C.c_int, C.c_uint32, f64p, C.POINTER(C.c_int), i32p]),
             "g2048o_env_reset": (None, [i32p, C.c_uint32, C.c_uint32]),
+            "g2048o_simulate_move": (C.c_int, [i32p, C.c_int, C.c_int32, i32p, f64p, u8p]),
             "g2048o_agent_move": (None, [i32p, C.c_int, i32p, i32p, C.POINTER(C.c_int)]),
             "g2048o_agent_valid_mask": (C.c_int, [i32p]),
             "g2048o_phase": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
@@ -151,6 +152,17 @@ def env_reset(h0, h1):
     b = np.zeros(16, dtype=np.int32)
     lib().g2048o_env_reset(_p(b, C.c_int32), h0, h1)
     return b
+
+
+def simulate_move(state, action, highest_tile):
+    """Returns (succ int32 (k,16), reward f64 (k,), done bool (k,))."""
+    b = _i32(state)
+    succ = np.zeros((32, 16), dtype=np.int32)
+    rw = np.zeros(32, dtype=np.float64)
+    dn = np.zeros(32, dtype=np.uint8)
+    k = lib().g2048o_simulate_move(_p(b, C.c_int32), action, int(highest_tile), _p(succ, C.c_int32), _p(rw, C.c_double),
+                                   _p(dn, C.c_uint8))
+    return succ[:k], rw[:k], dn[:k].astype(bool)
 
 
 def agent_move(board, action):

@@ -441,6 +441,39 @@ def gen_episodes():
     print("episodes: c1 dones", int(np.sum(c1["done"])))
 
 
+def gen_simulate(pool):
+    """Game2048Env.simulate_move (game_2048.py:341-387): all (cell, tile) successors with reward and done, for
+    env.highest_tile both equal to max(state) (as inside an episode) and larger (milestone branch fires)."""
+    env = Game2048Env()
+    n = pool.shape[0]
+    rng = np.random.default_rng(31)
+    actions = rng.integers(0, 4, size=n).astype(np.uint8)
+    hi_code = np.zeros(n, np.uint8)
+    count = np.zeros(n, np.uint8)
+    succ = np.zeros((n, 32, 16), np.uint8)
+    reward = np.zeros((n, 32), np.float64)
+    done = np.zeros((n, 32), np.uint8)
+    for i in range(n):
+        t = tiles_of(pool[i])
+        mx = int(pool[i].max())
+        hc = mx if i % 3 else min(mx + 1 + (i % 7), 17)         # every third row: highest_tile above the board's max
+        hi_code[i] = hc
+        set_env(env, np.zeros(16, np.int32), 123)                # the env's own board / score must come back untouched
+        env.board[0, 0] = 2
+        env.highest_tile = np.int32(1 << hc) if hc else np.int32(0)
+        res = env.simulate_move(t.copy(), int(actions[i]))
+        assert env.score == 123 and env.board[0, 0] == 2
+        count[i] = len(res)
+        for k, (ns, r, d) in enumerate(res):
+            succ[i, k] = codes_of(ns)
+            reward[i, k] = float(r)
+            done[i, k] = bool(d)
+    np.savez_compressed(os.path.join(HERE, "simulate_move.npz"), board=pool, action=actions, highest_code=hi_code,
+                        count=count, succ=succ, reward=reward, done=done)
+    print("simulate_move", n, "non-empty", int((count > 0).sum()), "max successors", int(count.max()),
+          "done successors", int(done.sum()))
+
+
 def gen_rng_pin():
     rows = []
     for seed in (0, 1, SEED, 2**63 + 12345, 2**64 - 1):
@@ -489,6 +522,7 @@ def main():
     small = np.concatenate([edges, pool[rng.choice(pool.shape[0], 1500, replace=False)]])
     gen_valid_and_agent_moves(small)
     gen_eval_scores(np.concatenate([edges, pool[rng.choice(pool.shape[0], 3000, replace=False)]]))
+    gen_simulate(np.concatenate([edges, pool[np.random.default_rng(97).choice(pool.shape[0], 1200, replace=False)]]))
     # beam roots: early/mid/late, few/many empties, single-valid-move, no-valid-move
     big = sp_greedy[sp_greedy.max(axis=1) >= 6]
     lift_all = np.concatenate([big, lifted(big, 1), lifted(big, 2), lifted(big, 3), lifted(big, 4)])

@@ -70,6 +70,21 @@ void hs_eval(const uint8_t *in, int kind, const uint8_t *phase, double *out, siz
     }
 }
 
+void hs_simulate(const uint8_t *in, const uint8_t *actions, const uint8_t *hc, uint8_t *succ, double *reward, uint8_t *done,
+                 uint8_t *count, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const Board state = ld(in + 16 * i);
+        Board moved; uint32_t gain;
+        const uint32_t ns = simulate_count(state, actions[i] & 3u, moved, gain);
+        count[i] = (uint8_t)ns;
+        for (uint32_t k = 0; k < ns; ++k) {
+            const SimOut o = simulate_successor(state, moved, gain, k, hc[i]);
+            st(succ + (i * 32 + k) * 16, o.board); reward[i * 32 + k] = o.reward; done[i * 32 + k] = o.done;
+        }
+    }
+}
+
 void hs_transpose(const uint8_t *in, uint8_t *out, uint8_t *rot, size_t n)
 {
     for (size_t i = 0; i < n; ++i) { st(out + 16 * i, transpose(ld(in + 16 * i))); st(rot + 16 * i, rot180(ld(in + 16 * i))); }

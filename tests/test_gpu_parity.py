@@ -290,3 +290,35 @@ def test_drop_in_env_single_step_rate(ops):
     dt = time.perf_counter() - t0
     print("drop-in Game2048Env: %.0f single-board steps/s (reference CPython env: ~2.3e3)" % (steps / dt))
     assert steps / dt > 1000
+
+
+def test_simulate_move_f4(ops, oracle):
+    """f4: Game2048Env.simulate_move -- all successors with the reference's quirks -- vs goldens taken from the
+    reference, vs the oracle on a larger random set, and through the drop-in class."""
+    g = load_golden("simulate_move.npz")
+    succ, rw, dn, cnt = ops.simulate_move(dev(g["board"]), dev(g["action"]), dev(g["highest_code"]))
+    assert np.array_equal(host(cnt), g["count"])
+    assert np.array_equal(host(succ), g["succ"])
+    assert np.array_equal(host(rw), g["reward"], equal_nan=True)          # f64 ==
+    assert np.array_equal(host(dn).astype(np.uint8), g["done"])
+    n = 20000
+    b = ops.synth_boards(n, seed=71, p_empty=0.35, max_code=12, device=DEV)
+    a = ops.synth_actions(n, seed=71, step_index=0, device=DEV)
+    succ, rw, dn, cnt = ops.simulate_move(b, a)                         # highest_tile = the state's own max
+    hb, ha = host(b), host(a); hs, hr, hd, hc = host(succ), host(rw), host(dn), host(cnt)
+    for i in range(0, n, 37):
+        t = tiles_of(hb[i])
+        s, r, d = oracle.simulate_move(t, int(ha[i]), int(t.max()))
+        assert hc[i] == s.shape[0], i
+        assert np.array_equal(tiles_of(hs[i, :hc[i]]), s) and np.array_equal(hr[i, :hc[i]], r) and np.array_equal(hd[i, :hc[i]], d), i
+    from environment.game_2048 import Game2048Env
+    env = Game2048Env(seed=9)
+    state = env.reset()
+    before = (env.board.copy(), env.score, env.highest_tile)
+    res = env.simulate_move(state, 2)
+    s, r, d = oracle.simulate_move(state, 2, int(env.highest_tile))
+    assert len(res) == s.shape[0]
+    for k, (ns, rr, dd) in enumerate(res):
+        assert ns.dtype == np.int32 and np.array_equal(ns, s[k]) and rr == r[k] and dd == bool(d[k])
+        assert isinstance(rr, np.float64) and isinstance(dd, bool)
+    assert np.array_equal(env.board, before[0]) and env.score == before[1] and env.highest_tile == before[2]

@@ -179,3 +179,16 @@ def test_eval_vs_golden_and_oracle(hs, oracle):
         pa = np.full(rb.shape[0], ph, np.uint8)
         assert np.array_equal(ev(rb, 1, pa), oracle.eval_batch(rb, oracle.EVAL_FULL, pa))
     assert np.array_equal(ev(rb, 2), oracle.eval_batch(rb, oracle.EVAL_PPO))
+
+
+def test_simulate_move_vs_golden(hs):
+    g = load_golden("simulate_move.npz")
+    b = np.ascontiguousarray(g["board"]); n = b.shape[0]
+    succ = np.zeros((n, 32, 16), np.uint8); rw = np.zeros((n, 32), np.float64)
+    dn = np.zeros((n, 32), np.uint8); cnt = np.zeros(n, np.uint8)
+    hs.hs_simulate(p(b), p(np.ascontiguousarray(g["action"])), p(np.ascontiguousarray(g["highest_code"])), p(succ),
+                   p(rw, C.c_double), p(dn), p(cnt), C.c_size_t(n))
+    assert np.array_equal(cnt, g["count"])
+    assert np.array_equal(succ, g["succ"])
+    assert np.array_equal(rw, g["reward"], equal_nan=True)
+    assert np.array_equal(dn, g["done"])

@@ -171,3 +171,19 @@ def test_config1_trace_batch_schedule(oracle):
         assert rw[0] == g["c1_reward"][t] and (fl[0] & 1) == g["c1_done"][t], t
         exp_score = 0 if g["c1_done"][t] else g["c1_score"][t]
         assert sc[0] == exp_score, t
+
+
+def test_simulate_move(oracle):
+    """Game2048Env.simulate_move incl. its accumulation quirk and the live milestone bonus."""
+    g = load_golden("simulate_move.npz")
+    fired = 0
+    for i in range(g["board"].shape[0]):
+        hc = int(g["highest_code"][i])
+        succ, rw, dn = oracle.simulate_move(tiles_of(g["board"][i]), int(g["action"][i]), (1 << hc) if hc else 0)
+        k = int(g["count"][i])
+        assert succ.shape[0] == k, i
+        assert np.array_equal(succ, tiles_of(g["succ"][i, :k])), i
+        assert np.array_equal(rw, g["reward"][i, :k], equal_nan=True), i          # f64 ==
+        assert np.array_equal(dn, g["done"][i, :k].astype(bool)), i
+        fired += int(k > 0 and hc > int(g["board"][i].max()))
+    assert fired > 100        # the milestone branch (dead inside step(), Q2) is exercised here
