@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-beam", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -194,6 +195,40 @@ def main():
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
                           "hbm_equivalent_GBs_at_29B": total_exp / bsec * BEAM_BYTES / 1e9}
+
+    # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
+    if not args.no_rollout and world == 1:
+        import torch.nn as nn
+        from g2048 import RolloutCollector
+
+        class Policy(nn.Module):            # the reference's models/transformer.py shape, stock torch, random init
+            def __init__(self):
+                super().__init__()
+                self.emb = nn.Linear(1, 64)
+                self.enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(64, 4, 128, batch_first=True), 2)
+                self.fc = nn.Sequential(nn.Linear(1024, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU())
+                self.actor, self.critic = nn.Linear(64, 4), nn.Linear(64, 1)
+
+            def forward(self, x):
+                h = self.fc(self.enc(self.emb(x.view(x.shape[0], 16, 1))).reshape(x.shape[0], -1))
+                return torch.softmax(self.actor(h), -1), self.critic(h)
+
+        class Uniform(nn.Module):           # no network: isolates the env side of the rollout
+            def forward(self, x):
+                return torch.full((x.shape[0], 4), 0.25, device=x.device)
+
+        torch.manual_seed(0)
+        rres = {}
+        for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("uniform_policy_env_only", Uniform())):
+            rc = RolloutCollector(65536, 128, pol, device=dev, seed=SEED)
+            rc.collect()
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            rc.collect()
+            torch.cuda.synchronize()
+            rres[name] = 65536 * 128 / (time.perf_counter() - r0)
+        result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps (obs -> mask -> policy -> sample -> step, auto-reset)",
+                             "unit": "env-steps/s", **rres}
 
     # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
