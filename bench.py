@@ -248,6 +248,13 @@ def main():
                                   "kind": "port",
                                   "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
                                             "(%.1f s, OpenMP static over boards)" % (passes, csec)}
+        from oracle import pyref
+        prate = pyref.time_steps(4000, SEED)
+        result["cpu_baseline_python"] = {"value": prate, "unit": "board-steps/s", "cores": 1, "kind": "port",
+                                         "sample": "4000 steps of one board, reference-style per-board NumPy env "
+                                                   "(oracle/pyref.py), auto-reset",
+                                         "calibration": "the reference's own Game2048Env ran at 0.88x this env's rate on "
+                                                        "the same core in the build container (2.55e3 vs 2.92e3 steps/s)"}
         # the last CPU pass doubles as a full-size parity check of what the GPU just computed
         one_step(W + passes - 1)
         torch.cuda.synchronize()
