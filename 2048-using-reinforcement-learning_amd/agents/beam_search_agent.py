@@ -26,6 +26,16 @@ class BeamSearchAgent:
         self.device = torch.device(device)
         self.seed = random.getrandbits(63) if seed is None else int(seed)
         self._calls = 0
+        self._init_patterns()
+
+    def _init_patterns(self):                                                           # reference :32-69
+        """The reference's public pattern tables, kept as attributes for API parity. Only snake_patterns[0]
+        takes part in the score (reference :369); it lives in the kernel as four v_dot4 weight words."""
+        self.snake_patterns = [np.array([[15, 14, 13, 12], [8, 9, 10, 11], [7, 6, 5, 4], [0, 1, 2, 3]]),
+                               np.arange(15, -1, -1).reshape(4, 4)]
+        base = np.arange(4)
+        self.gradients = [4 + base[:, None] - base[None, :], 7 - base[:, None] - base[None, :]]
+        self.corners = [(0, 0), (0, 3), (3, 0), (3, 3)]
 
     def get_action(self, state, valid_moves=None):                                      # reference :71-181
         if self.device.type != "cuda":
