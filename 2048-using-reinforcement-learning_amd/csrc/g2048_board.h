@@ -35,7 +35,7 @@ constexpr uint32_t B80 = 0x80808080u;
 constexpr uint32_t B7F = 0x7f7f7f7fu;
 
 // RNG domains (DESIGN.md "RNG")
-enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6 };
+enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6, DOM_POLICY = 7 };
 
 // ---------------------------------------------------------------- intrinsics --
 // v_perm_b32: bytes of {s0:s1} (s1 = bytes 0..3, s0 = bytes 4..7) picked by the
@@ -415,6 +415,28 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
     o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);
     o.board = cur;
     return o;
+}
+
+// ---------------------------------------------------------------- policy ------
+// Masked categorical sampling of PPOAgent.get_action (agents/ppo_agent.py:211-221) for one env: the reference
+// samples from softmax(log(p + 1e-10) + mask), i.e. from weights w_a = p_a + 1e-10 on the valid actions. Here:
+// inverse CDF in f32 with one 32-bit draw h (u = (h >> 8) * 2^-24), sums taken left to right; returns the action
+// and its probability w_a / sum (the caller takes the log). A mask with no valid action samples unmasked.
+G2048_HD uint32_t sample_action(float p0, float p1, float p2, float p3, uint32_t mask4, uint32_t h, float &prob)
+{
+    const uint32_t m = (mask4 & 15u) ? (mask4 & 15u) : 15u;
+    const float w0 = (m & 1u) ? p0 + 1e-10f : 0.0f, w1 = (m & 2u) ? p1 + 1e-10f : 0.0f;
+    const float w2 = (m & 4u) ? p2 + 1e-10f : 0.0f, w3 = (m & 8u) ? p3 + 1e-10f : 0.0f;
+    const float c0 = w0, c1 = c0 + w1, c2 = c1 + w2, sum = c2 + w3;
+    const float t = ((float)(h >> 8) * 5.9604644775390625e-08f) * sum;
+    uint32_t a = 3u;
+    if (t < c2) a = 2u;
+    if (t < c1) a = 1u;
+    if (t < c0) a = 0u;
+    if (!((m >> a) & 1u)) a = 31u - (uint32_t)__builtin_clz(m);      // rounding fell past the last valid action
+    const float wa = a == 0u ? w0 : a == 1u ? w1 : a == 2u ? w2 : w3;
+    prob = wa / sum;
+    return a;
 }
 
 // --------------------------------------------------------- simulate_move ------

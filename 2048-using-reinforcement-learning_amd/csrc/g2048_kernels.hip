@@ -122,6 +122,20 @@ __global__ __launch_bounds__(kBlock) void valid_kernel(const uint4 *__restrict__
     mask_out[i] = (uint8_t)(AGENT ? valid_mask_agent(b, false) : valid_mask_env(b));
 }
 
+// ----------------------------------------------------------------- policy -----
+__global__ __launch_bounds__(kBlock) void sample_kernel(const float4 *__restrict__ probs, const uint8_t *__restrict__ mask,
+                                                       uint8_t *__restrict__ actions, float *__restrict__ prob_out,
+                                                       uint32_t k0, uint32_t k1, uint64_t id_base, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = probs[i];
+    float pa;
+    const uint32_t a = sample_action(p.x, p.y, p.z, p.w, mask ? (uint32_t)mask[i] : 15u, rng_draw(k0, k1, id_base + i, 0u), pa);
+    actions[i] = (uint8_t)a;
+    prob_out[i] = pa;
+}
+
 // ---------------------------------------------------------- simulate_move -----
 // 32 lanes per board (at most 15 empty cells x 2 tiles = 30 successors), lane k builds successor k.
 __global__ __launch_bounds__(kBlock) void simulate_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ actions,
@@ -343,6 +357,18 @@ int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t
     if (opts == G2048_VALID_AGENT) hipLaunchKernelGGL(valid_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     else hipLaunchKernelGGL(valid_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     return check_launch("g2048_valid_moves");
+}
+
+int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                         uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!probs || !actions_out || !prob_out) return fail(G2048_ERR_ARG, "g2048_sample_actions: null pointer");
+    if (!aligned16(probs) || !aligned4(prob_out)) return fail(G2048_ERR_ARG, "g2048_sample_actions: misaligned array");
+    const Keys k = rng_keys(seed, DOM_POLICY, step_index);
+    hipLaunchKernelGGL(sample_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4 *>(probs), mask4_or_null, actions_out, prob_out, k.k0, k.k1, env_id_base, n);
+    return check_launch("g2048_sample_actions");
 }
 
 int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null, void *succ_boards_out,

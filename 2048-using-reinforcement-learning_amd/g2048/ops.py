@@ -94,6 +94,26 @@ def obs(boards, out=None):
     return out
 
 
+def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, actions=None, prob=None):
+    """Masked categorical sampling (PPOAgent.get_action, agents/ppo_agent.py:211-221) for every env in one kernel.
+    probs float32 (n,4); mask4 uint8 (n,) or None. Returns (actions uint8 (n,), prob float32 (n,))."""
+    L.require_device_tensor(probs, torch.float32, (4,), "probs")
+    n = probs.shape[0]
+    if mask4 is not None:
+        L.require_device_tensor(mask4, torch.uint8, None, "mask4")
+    dev = probs.device
+    if actions is None:
+        actions = torch.empty(n, dtype=torch.uint8, device=dev)
+    if prob is None:
+        prob = torch.empty(n, dtype=torch.float32, device=dev)
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    L.require_device_tensor(prob, torch.float32, None, "prob")
+    L.check(L.lib().g2048_sample_actions(probs.data_ptr(), mask4.data_ptr() if mask4 is not None else None,
+                                         actions.data_ptr(), prob.data_ptr(), L.u64(seed), L.u64(step_index),
+                                         L.u64(id_base), n, L.stream_ptr(dev)))
+    return actions, prob
+
+
 def simulate_move(boards, actions, highest_code=None):
     """Game2048Env.simulate_move for every (board, action) (environment/game_2048.py:341-387).
     Returns (succ uint8 (n,32,16), reward float64 (n,32), done bool (n,32), count uint8 (n,)); only the first

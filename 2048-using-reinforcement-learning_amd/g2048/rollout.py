@@ -30,12 +30,15 @@ def masked_sample(probs, mask4, generator=None):
 
 class RolloutCollector:
     def __init__(self, n_envs, n_steps, policy, device="cuda", seed=0x2048, id_base=0, shaping=False,
-                 generator=None):
+                 generator=None, sampler="fused"):
         self.n, self.T = int(n_envs), int(n_steps)
         self.device = torch.device(device)
         self.policy = policy
         self.shaping = bool(shaping)
         self.generator = generator
+        if sampler not in ("fused", "torch"):
+            raise ValueError("sampler must be 'fused' (g2048_sample_actions, counter RNG) or 'torch' (masked_sample)")
+        self.sampler = sampler
         self.env = VecGame2048(self.n, device=self.device, seed=seed, id_base=id_base, auto_reset=True)
         d, T, n = self.device, self.T, self.n
         self.obs = torch.empty((T, n, 16), dtype=torch.float32, device=d)
@@ -58,9 +61,14 @@ class RolloutCollector:
             ops.valid_moves(env.boards, out=self.masks[t])
             out = self.policy(self.obs[t])
             probs, value = out if isinstance(out, (tuple, list)) else (out, None)
-            a, lp = masked_sample(probs, self.masks[t], self.generator)
-            self.actions[t].copy_(a)
-            self.logp[t].copy_(lp)
+            if self.sampler == "fused":      # one kernel: draw keyed by (seed, POLICY, step, global env id)
+                ops.sample_actions(probs.float().contiguous(), self.masks[t], env.seed, env.t, env.id_base,
+                                   actions=self.actions[t], prob=self.logp[t])
+                torch.log_(self.logp[t])
+            else:
+                a, lp = masked_sample(probs, self.masks[t], self.generator)
+                self.actions[t].copy_(a)
+                self.logp[t].copy_(lp)
             if value is not None:
                 self.values[t].copy_(value.reshape(-1))
             # step in place on the env's buffers, reward / flags written straight into the trajectory

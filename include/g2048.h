@@ -115,6 +115,14 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
                           uint32_t opts, void *stream);
 
+/* The masked sampling of PPOAgent.get_action (agents/ppo_agent.py:211-221) for n envs: probs is float32 [n][4]
+ * (the actor's softmax output), mask4 as g2048_valid_moves writes it (NULL = all valid). The action is drawn from
+ * weights p_a + 1e-10 over the valid actions (what Categorical(logits = log(p + 1e-10) + mask) samples) by inverse
+ * CDF with draw (seed, POLICY, step_index, env_id_base + i); prob_out[i] = its probability (take the log for
+ * the reference's `action_prob`). */
+int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                         uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream);
+
 /* Game2048Env.simulate_move (environment/game_2048.py:341-387) for n (state, action) pairs: every successor the
  * reference lists -- 2 per empty cell of the moved board, at most 30 -- in its order and with its behaviour (each
  * successor is built on top of the previous one; its reward is computed on the previous successor's board and

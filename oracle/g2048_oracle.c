@@ -571,6 +571,37 @@ double g2048o_ppo_shaping(const int32_t b[16], double reward_in)
     return reward;
 }
 
+/* Masked sampling of PPOAgent.get_action (agents/ppo_agent.py:211-221): weights p_a + 1e-10 on the valid actions
+ * (what Categorical(logits = log(p + 1e-10) + mask) samples from); the build's sampler is an f32 inverse CDF over
+ * one 32-bit draw (DESIGN.md "RNG"), restated here operation by operation.                                   */
+int g2048o_sample_action(const float p[4], int mask4, uint32_t h, float *prob)
+{
+    int m = (mask4 & 15) ? (mask4 & 15) : 15;
+    float w[4], c[4];
+    for (int a = 0; a < 4; ++a) w[a] = ((m >> a) & 1) ? p[a] + 1e-10f : 0.0f;
+    c[0] = w[0]; c[1] = c[0] + w[1]; c[2] = c[1] + w[2]; c[3] = c[2] + w[3];
+    float u = (float)(h >> 8) * 5.9604644775390625e-08f;          /* 2^-24 */
+    float t = u * c[3];
+    int a = 3;
+    if (t < c[2]) a = 2;
+    if (t < c[1]) a = 1;
+    if (t < c[0]) a = 0;
+    if (!((m >> a) & 1)) { a = 3; while (!((m >> a) & 1)) --a; }
+    *prob = w[a] / c[3];
+    return a;
+}
+
+void g2048o_sample_batch(const float *probs, const uint8_t *mask_or_null, uint8_t *actions, float *prob,
+                         uint64_t seed, uint64_t step_index, uint64_t id_base, size_t n)
+{
+    uint32_t k0, k1;
+    g2048o_rng_keys(seed, 7 /* POLICY */, step_index, &k0, &k1);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i)
+        actions[i] = (uint8_t)g2048o_sample_action(probs + 4 * i, mask_or_null ? mask_or_null[i] : 15,
+                                                   g2048o_rng_draw(k0, k1, id_base + i, 0), prob + i);
+}
+
 /* ------------------------------------------------------ batched forms ---- */
 void g2048o_synth_boards(uint8_t *codes, uint64_t seed, uint64_t id_base, size_t n,
                          uint32_t p_empty_u16, uint32_t max_code)

@@ -76,6 +76,8 @@ def lib():
             "g2048o_obs_batch": (None, [u8p, f32p, C.c_size_t]),
             "g2048o_beam_batch": (None, [u8p, u8p, u8p, f32p, u32p, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                          C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
+            "g2048o_sample_action": (C.c_int, [f32p, C.c_int, C.c_uint32, f32p]),
+            "g2048o_sample_batch": (None, [f32p, u8p, u8p, f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
             "g2048o_num_threads": (C.c_int, []),
             "g2048o_set_num_threads": (None, [C.c_int]),
         }
@@ -291,6 +293,16 @@ def beam_batch(roots, width, depth, mask=None, early_thr=512, mid_thr=1024, seed
                             _p(exp, C.c_uint32), width, depth, early_thr, mid_thr, seed, step_index,
                             game_id_base, n)
     return act, prob, exp
+
+
+def sample_batch(probs, mask=None, seed=0x2048, step_index=0, id_base=0):
+    pr = np.ascontiguousarray(probs, dtype=np.float32).reshape(-1, 4)
+    mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    act = np.empty(pr.shape[0], dtype=np.uint8)
+    pa = np.empty(pr.shape[0], dtype=np.float32)
+    lib().g2048o_sample_batch(_p(pr, C.c_float), _p(mk, C.c_uint8), _p(act, C.c_uint8), _p(pa, C.c_float),
+                              seed, step_index, id_base, pr.shape[0])
+    return act, pa
 
 
 def num_threads():

@@ -85,6 +85,12 @@ void hs_simulate(const uint8_t *in, const uint8_t *actions, const uint8_t *hc, u
     }
 }
 
+void hs_sample(const float *probs, const uint8_t *mask, const uint32_t *h, uint8_t *actions, float *prob, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        actions[i] = (uint8_t)sample_action(probs[4 * i], probs[4 * i + 1], probs[4 * i + 2], probs[4 * i + 3], mask[i], h[i], prob[i]);
+}
+
 void hs_transpose(const uint8_t *in, uint8_t *out, uint8_t *rot, size_t n)
 {
     for (size_t i = 0; i < n; ++i) { st(out + 16 * i, transpose(ld(in + 16 * i))); st(rot + 16 * i, rot180(ld(in + 16 * i))); }

@@ -86,3 +86,26 @@ def test_config4_rollout_65536x128(g2048, oracle):
     print("config 4: %d env-steps in %.3f s = %.3e env-steps/s end-to-end (transformer policy)" % (n * T, dt, n * T / dt))
     replay_and_check(oracle, res, n, T, 0x2048)
     assert int(res["dones"].sum()) > 0          # random-ish policy: episodes end inside 128 steps and auto-reset
+
+
+def test_fused_sampler_vs_oracle(g2048, oracle):
+    from g2048 import ops
+    torch.manual_seed(4)
+    n = 300000
+    probs = torch.softmax(torch.randn(n, 4, device=DEV) * 2, dim=1)
+    probs[:64] = 0
+    mask = torch.randint(0, 16, (n,), dtype=torch.uint8, device=DEV)
+    a, pa = ops.sample_actions(probs, mask, seed=21, step_index=6, id_base=1000)
+    oa, op = oracle.sample_batch(probs.cpu().numpy(), mask.cpu().numpy(), seed=21, step_index=6, id_base=1000)
+    assert np.array_equal(a.cpu().numpy(), oa)
+    assert np.array_equal(pa.cpu().numpy().view(np.uint32), op.view(np.uint32))          # f32 bit-exact
+    a2, _ = ops.sample_actions(probs, None, seed=21, step_index=6, id_base=1000)
+    oa2, _ = oracle.sample_batch(probs.cpu().numpy(), None, seed=21, step_index=6, id_base=1000)
+    assert np.array_equal(a2.cpu().numpy(), oa2)
+
+
+def test_rollout_torch_sampler_still_available(g2048, oracle):
+    torch.manual_seed(5)
+    pol = TinyTransformerPolicy().to(DEV).eval()
+    rc = g2048.RolloutCollector(1024, 16, pol, device=DEV, seed=3, sampler="torch")
+    replay_and_check(oracle, rc.collect(), 1024, 16, 3)

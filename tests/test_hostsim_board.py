@@ -192,3 +192,27 @@ def test_simulate_move_vs_golden(hs):
     assert np.array_equal(succ, g["succ"])
     assert np.array_equal(rw, g["reward"], equal_nan=True)
     assert np.array_equal(dn, g["done"])
+
+
+def test_sample_action_vs_oracle_and_distribution(hs, oracle):
+    rng = np.random.default_rng(3)
+    n = 200000
+    logits = rng.normal(size=(n, 4)).astype(np.float32) * 2
+    probs = (np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)).astype(np.float32)
+    probs[:100] = 0.0                                   # degenerate rows
+    mask = rng.integers(0, 16, size=n).astype(np.uint8)
+    k0, k1 = oracle.rng_keys(5, 7, 9)
+    h = np.array([oracle.rng_draw(k0, k1, i, 0) for i in range(n)], np.uint32)
+    act = np.empty(n, np.uint8); pa = np.empty(n, np.float32)
+    hs.hs_sample(p(np.ascontiguousarray(probs), C.c_float), p(mask), p(h, C.c_uint32), p(act), p(pa, C.c_float), C.c_size_t(n))
+    oa, op = oracle.sample_batch(probs, mask, seed=5, step_index=9)
+    assert np.array_equal(act, oa) and np.array_equal(pa.view(np.uint32), op.view(np.uint32))
+    m = np.where(mask == 0, 15, mask)
+    assert bool((((m >> act) & 1) == 1).all())          # never an invalid action
+    # distribution: for one fixed row, empirical frequencies ~ masked renormalised probabilities
+    row = np.array([[0.5, 0.2, 0.2, 0.1]], np.float32).repeat(n, 0)
+    mk = np.full(n, 0b1011, np.uint8)
+    hs.hs_sample(p(np.ascontiguousarray(row), C.c_float), p(mk), p(h, C.c_uint32), p(act), p(pa, C.c_float), C.c_size_t(n))
+    freq = np.bincount(act, minlength=4) / n
+    assert freq[2] == 0 and np.allclose(freq[[0, 1, 3]], np.array([0.5, 0.2, 0.1]) / 0.8, atol=0.005)
+    assert np.allclose(pa[act == 0], 0.5 / 0.8, rtol=1e-6)
