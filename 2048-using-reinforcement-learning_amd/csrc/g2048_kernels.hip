@@ -308,23 +308,20 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, 
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
-    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | (15u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | (3u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
     const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *in = static_cast<const uint4 *>(boards_in);
     uint4 *out = static_cast<uint4 *>(boards_out);
     const bool f64 = opts & G2048_STEP_REWARD_F64, ar = opts & G2048_STEP_AUTO_RESET;
     const unsigned tune = (opts >> G2048_STEP_TUNE_SHIFT) & 3u;            // 0 = default
-    const unsigned tune_block = (opts >> (G2048_STEP_TUNE_SHIFT + 2)) & 3u;  // 0 = default (256), 1/2/3 = 64/128/512
     const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : kStepBoardsPerLane;
-#define G2048_LAUNCH_STEP(F, A, BB, BLK) \
-    hipLaunchKernelGGL((step_kernel<F, A, BB, BLK>), dim3(blocks_for(n, BLK * BB)), dim3(BLK), 0, s, in, actions, out, \
+#define G2048_LAUNCH_STEP(F, A, BB) \
+    hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, in, actions, out, \
                        score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n)
 #define G2048_LAUNCH_STEP_B(F, A) \
-    do { if (tune_block == 1) G2048_LAUNCH_STEP(F, A, 1, 64); else if (tune_block == 2) G2048_LAUNCH_STEP(F, A, 1, 128); \
-         else if (tune_block == 3) G2048_LAUNCH_STEP(F, A, 1, 512); \
-         else if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1, 256); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2, 256); \
-         else G2048_LAUNCH_STEP(F, A, 4, 256); } while (0)
+    do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
+         else G2048_LAUNCH_STEP(F, A, 4); } while (0)
     if (f64 && ar) G2048_LAUNCH_STEP_B(true, true);
     else if (f64) G2048_LAUNCH_STEP_B(true, false);
     else if (ar) G2048_LAUNCH_STEP_B(false, true);

@@ -35,7 +35,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(out, torch.uint8, (16,), "out")
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
-    opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) | ((int(tune) & 15) << 8)
+    opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) | ((int(tune) & 3) << 8)
     L.check(L.lib().g2048_step(boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
                                reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base),
                                n, opts, L.stream_ptr(dev)))

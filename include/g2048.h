@@ -51,8 +51,7 @@ enum {
 #define G2048_STEP_REWARD_F64  0x01u   /* reward_out is double[n] (parity mode); default float[n] = (float)f64 reward */
 #define G2048_STEP_AUTO_RESET  0x02u   /* finished boards are replaced by a fresh episode (score 0); flags keep DONE */
 
-/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant (0 = library default, 1/2/3 = 1/2/4),
- * bits 10..11 the workgroup size (0 = default 256, 1/2/3 = 64/128/512) */
+/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4 */
 #define G2048_STEP_TUNE_SHIFT  8
 
 /* opts of g2048_valid_moves */
