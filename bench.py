@@ -64,9 +64,12 @@ def main():
     local_dev = local_rank % ndev            # normally local_rank; a 2-rank rehearsal on one GPU shares cuda:0
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    if rank == 0:
+        ge.ensure_built()
     ge.import_package()
     from g2048 import ops, _lib, dist as gdist
     gdist.init("nccl", dev)
+    gdist.barrier()             # rank 0 may just have built the library
     _lib.lib()
     assert ops.selftest(dev) == 0, "device self-test failed"
 

@@ -12,6 +12,7 @@ DEV = "cuda:0"
 @pytest.fixture(scope="module")
 def ops():
     import __graft_entry__ as ge
+    ge.ensure_built()
     ge.import_package()
     from g2048 import ops as o
     return o

@@ -14,6 +14,7 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)
 @pytest.fixture(scope="module")
 def g2048():
     import __graft_entry__ as ge
+    ge.ensure_built()
     return ge.import_package()
 
 

@@ -16,6 +16,7 @@ SEED = 0x2048
 @pytest.fixture(scope="module")
 def ops():
     import __graft_entry__ as ge
+    ge.ensure_built()
     ge.import_package()
     from g2048 import ops as o, _lib
     _lib.lib()

@@ -31,6 +31,7 @@ class TinyTransformerPolicy(nn.Module):
 @pytest.fixture(scope="module")
 def g2048():
     import __graft_entry__ as ge
+    ge.ensure_built()
     return ge.import_package()
 
 
