@@ -379,6 +379,38 @@ def gen_beam(roots, with_mask):
           "prob!=1:", int((rows[:, 5] != 1.0).sum()))
 
 
+def gen_beam_masks(roots):
+    """get_action with ARBITRARY caller masks, including ones that disagree with the agent's own validity:
+    reaches the random fallback (beam_search_agent.py:126-128: random.choice(valid_actions), prob 0.5)."""
+    rng = np.random.default_rng(123)
+    agent = BeamSearchAgent(beam_width=5, search_depth=6)
+    rows = []
+    for ri in range(roots.shape[0]):
+        t = tiles_of(roots[ri])
+        for rep in range(3):
+            mask = int(rng.integers(0, 16))
+            vm = [bool((mask >> a) & 1) for a in range(4)]
+            gid = 5000 + 3 * ri + rep
+            k0, k1 = O.rng_keys(SEED, O.DOM_BEAM, 1)
+            ctr = [0]
+
+            def src():
+                h = O.rng_draw(k0, k1, gid, ctr[0])
+                ctr[0] += 1
+                return h
+            STREAM.source = src
+            STREAM.consumed = 0
+            a, p = agent.get_action(t.copy(), vm)
+            rows.append((ri, mask, gid, int(a), float(p), STREAM.consumed))
+    rows = np.array(rows, dtype=np.float64)
+    fallback = int(((rows[:, 4] == 0.5) & (rows[:, 1] != 0)).sum())
+    np.savez_compressed(os.path.join(HERE, "beam_masks.npz"), root=roots, root_index=rows[:, 0].astype(np.int32),
+                        mask=rows[:, 1].astype(np.int32), game_id=rows[:, 2].astype(np.int64),
+                        action=rows[:, 3].astype(np.int32), prob=rows[:, 4].astype(np.float32),
+                        consumed=rows[:, 5].astype(np.int32), seed=np.uint64(SEED), step_index=np.uint64(1))
+    print("beam_masks", rows.shape[0], "random-fallback decisions", fallback)
+
+
 def gen_episodes():
     """Full seeded episodes (reset spawns included) + the 1000-step config-1 trace with auto-reset."""
     env = Game2048Env()
@@ -540,6 +572,8 @@ def main():
     ]).astype(np.uint8)
     print("beam roots", roots.shape)
     gen_beam(roots, with_mask=True)
+    gen_beam_masks(np.concatenate([edges, random_code_boards(np.random.default_rng(321), 60, 0.05, 4),
+                                   random_code_boards(np.random.default_rng(322), 25, 0.4, 8)]).astype(np.uint8))
     gen_episodes()
     print("done in %.1fs" % (time.time() - t0))
 

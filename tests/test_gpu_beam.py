@@ -96,3 +96,17 @@ def test_drop_in_classes_train_loop(ops, oracle):
     assert env.get_valid_moves() == [True, True, True, True]
     s, r, d, info = env.step(0)
     assert s[0] == 4 and info["valid_move"]
+
+
+def test_beam_arbitrary_masks_and_random_fallback(ops):
+    """Golden decisions taken from the reference with adversarial caller masks (random fallback included)."""
+    g = load_golden("beam_masks.npz")
+    seed, si = int(g["seed"]), int(g["step_index"])
+    roots = dev(g["root"][g["root_index"]])
+    bad = []
+    for i in range(g["mask"].shape[0]):
+        m = torch.tensor([int(g["mask"][i])], dtype=torch.uint8, device=DEV)
+        a, p = ops.beam_get_action(roots[i:i + 1], 5, 6, m, seed=seed, step_index=si, game_id_base=int(g["game_id"][i]))
+        if int(a.item()) != g["action"][i] or float(p.item()) != g["prob"][i]:
+            bad.append(i)
+    assert not bad, bad

@@ -187,3 +187,16 @@ def test_simulate_move(oracle):
         assert np.array_equal(dn, g["done"][i, :k].astype(bool)), i
         fired += int(k > 0 and hc > int(g["board"][i].max()))
     assert fired > 100        # the milestone branch (dead inside step(), Q2) is exercised here
+
+
+def test_beam_arbitrary_masks_and_random_fallback(oracle):
+    """Caller masks that disagree with the agent's own validity, incl. the random fallback (:126-128)."""
+    g = load_golden("beam_masks.npz")
+    seed, si = int(g["seed"]), int(g["step_index"])
+    fb = 0
+    for i in range(g["mask"].shape[0]):
+        r = oracle.beam_get_action(tiles_of(g["root"][g["root_index"][i]]), int(g["mask"][i]), 5, 6, seed=seed,
+                                   step_index=si, game_id=int(g["game_id"][i]))
+        assert (r["action"], r["prob"], r["consumed"]) == (g["action"][i], g["prob"][i], g["consumed"][i]), i
+        fb += int(g["prob"][i] == 0.5 and g["mask"][i] != 0)
+    assert fb >= 5
