@@ -5,6 +5,33 @@ from . import _lib as L
 from . import ops
 
 
+class _StepInfo(dict):
+    """info dict of VecGame2048.step, computed on access (a step itself launches one kernel and nothing else).
+    Keys as the reference's (environment/game_2048.py:206-210): score, valid_move, highest_tile. Views of the
+    env's live buffers: read them before the next step."""
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+
+    def __missing__(self, key):
+        e = self._env
+        if key == "score":
+            v = e.scores
+        elif key == "valid_move":
+            v = (e.flags & L.FLAG_VALID).bool()
+        elif key == "highest_tile":
+            code = (e.flags >> L.FLAG_MAXCODE_SHIFT).int()
+            v = torch.where(code > 0, torch.ones_like(code) << code, torch.zeros_like(code))
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+    def keys(self):
+        return ["score", "valid_move", "highest_tile"]
+
+
 class VecGame2048:
     """n independent Game2048Env instances living in HBM (reference environment/game_2048.py:4-210).
 
@@ -57,13 +84,7 @@ class VecGame2048:
         self.boards, self._spare = self._spare, self.boards
         self.t += 1
         done = (self.flags & L.FLAG_DONE).bool()
-        info = {
-            "score": self.scores,
-            "valid_move": (self.flags & L.FLAG_VALID).bool(),
-            "highest_tile": torch.where(self.flags >> L.FLAG_MAXCODE_SHIFT > 0,
-                                        torch.ones((), dtype=torch.int32, device=self.device) << (self.flags >> L.FLAG_MAXCODE_SHIFT).int(),
-                                        torch.zeros((), dtype=torch.int32, device=self.device)),
-        }
+        info = _StepInfo(self)
         return self.boards, self.reward, done, info
 
     def valid_moves(self, agent_semantics=False):
