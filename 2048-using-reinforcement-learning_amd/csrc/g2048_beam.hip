@@ -165,7 +165,6 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
         uint32_t rank[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) rank[p] = 0u;
-        const uint32_t nround = (total_valid + 63u) & ~63u;                       // entries beyond total_valid hold 0 / -inf
         if (fast) {
             const uint4 *keys = reinterpret_cast<const uint4 *>(s_score);
             for (uint32_t j = 0; j < total_valid; j += 4) {
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                 }
             }
         }
-        (void)nround;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const uint32_t ci = (uint32_t)(p * 64) + lane;

@@ -12,6 +12,11 @@ def _dev(t):
     return t.device
 
 
+def _require_scores(scores):
+    """scores are 32-bit on the device (the ABI's uint32); torch code usually holds them as int32."""
+    L.require_device_tensor(scores, torch.uint32 if scores.dtype == torch.uint32 else torch.int32, None, "scores")
+
+
 def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=None, flags=None,
          reward_f64=False, auto_reset=False, tune=0):
     """Game2048Env.step for every board (reference environment/game_2048.py:170-210).
@@ -21,7 +26,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     n = boards.shape[0]
     L.require_device_tensor(actions, torch.uint8, None, "actions")
-    L.require_device_tensor(scores, torch.int32 if scores.dtype == torch.int32 else torch.uint32, None, "scores")
+    _require_scores(scores)
     if actions.shape[0] != n or scores.shape[0] != n:
         raise ValueError("g2048: actions/scores length must equal the number of boards")
     dev = _dev(boards)
@@ -50,7 +55,7 @@ def reset(n, seed, epoch=0, id_base=0, device="cuda", boards=None, scores=None):
     if scores is None:
         scores = torch.empty(n, dtype=torch.int32, device=dev)
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
-    L.require_device_tensor(scores, scores.dtype if scores.dtype in (torch.int32, torch.uint32) else torch.int32, None, "scores")
+    _require_scores(scores)
     L.check(L.lib().g2048_reset(boards.data_ptr(), scores.data_ptr(), L.u64(seed), L.u64(epoch), L.u64(id_base),
                                 boards.shape[0], L.stream_ptr(dev)))
     return boards, scores
