@@ -122,6 +122,37 @@ __global__ __launch_bounds__(kBlock) void valid_kernel(const uint4 *__restrict__
     mask_out[i] = (uint8_t)(AGENT ? valid_mask_agent(b, false) : valid_mask_env(b));
 }
 
+// ------------------------------------------------------- episode tracking -----
+// The per-move bookkeeping of the reference's evaluation loop (evaluate_beam_search.py:42-64, run_evaluation.py
+// :56-69) for every game of a batch, after a step: milestone tiles 64..8192 record the move index at which they
+// were first reached, valid / invalid move counters, move counter, and the game leaves the `alive` set when done.
+__global__ __launch_bounds__(kBlock) void track_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ expanded,
+                                                      uint8_t *__restrict__ alive, int32_t *__restrict__ moves,
+                                                      int32_t *__restrict__ valid_cnt, int32_t *__restrict__ invalid_cnt,
+                                                      int4 *__restrict__ milestone, unsigned long long *__restrict__ expanded_sum,
+                                                      int32_t move_index, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (!alive[i]) return;
+    const uint32_t f = flags[i];
+    const int32_t maxcode = (int32_t)(f >> G2048_FLAG_MAXCODE_SHIFT);
+    int4 lo = milestone[2 * i], hi = milestone[2 * i + 1];               // codes 6..9 and 10..13
+    if (lo.x < 0 && maxcode >= 6) lo.x = move_index;
+    if (lo.y < 0 && maxcode >= 7) lo.y = move_index;
+    if (lo.z < 0 && maxcode >= 8) lo.z = move_index;
+    if (lo.w < 0 && maxcode >= 9) lo.w = move_index;
+    if (hi.x < 0 && maxcode >= 10) hi.x = move_index;
+    if (hi.y < 0 && maxcode >= 11) hi.y = move_index;
+    if (hi.z < 0 && maxcode >= 12) hi.z = move_index;
+    if (hi.w < 0 && maxcode >= 13) hi.w = move_index;
+    milestone[2 * i] = lo; milestone[2 * i + 1] = hi;
+    if (f & G2048_FLAG_VALID) valid_cnt[i] += 1; else invalid_cnt[i] += 1;
+    moves[i] += 1;
+    if (expanded && expanded_sum) expanded_sum[i] += expanded[i];
+    if (f & G2048_FLAG_DONE) alive[i] = 0;
+}
+
 // ----------------------------------------------------------------- policy -----
 __global__ __launch_bounds__(kBlock) void sample_kernel(const float4 *__restrict__ probs, const uint8_t *__restrict__ mask,
                                                        uint8_t *__restrict__ actions, float *__restrict__ prob_out,
@@ -354,6 +385,20 @@ int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t
     if (opts == G2048_VALID_AGENT) hipLaunchKernelGGL(valid_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     else hipLaunchKernelGGL(valid_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, s, b, mask4_out, n);
     return check_launch("g2048_valid_moves");
+}
+
+int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+                         int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
+                         unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!flags || !alive_inout || !moves_inout || !valid_inout || !invalid_inout || !milestone_move_inout)
+        return fail(G2048_ERR_ARG, "g2048_track_episodes: null pointer");
+    if (!aligned16(milestone_move_inout)) return fail(G2048_ERR_ARG, "g2048_track_episodes: milestone array must be 16-byte aligned");
+    hipLaunchKernelGGL(track_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), flags,
+                       expanded_or_null, alive_inout, moves_inout, valid_inout, invalid_inout,
+                       reinterpret_cast<int4 *>(milestone_move_inout), expanded_sum_inout_or_null, move_index, n);
+    return check_launch("g2048_track_episodes");
 }
 
 int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,

@@ -23,7 +23,7 @@ from . import _lib as L
 from . import ops
 from .vec import VecGame2048
 
-MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_search.py:42-43
+MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_search.py:42-43 (fixed in the kernel)
 
 
 def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
@@ -33,32 +33,24 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
     n = int(num_games)
     t_start = time.perf_counter()
     env = VecGame2048(n, device=dev, seed=seed, id_base=game_id_base)
-    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    alive = torch.ones(n, dtype=torch.uint8, device=dev)
     moves = torch.zeros(n, dtype=torch.int32, device=dev)
     valid_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     invalid_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-    ms_codes = torch.tensor([m.bit_length() - 1 for m in MILESTONES], dtype=torch.uint8, device=dev)
     ms_move = torch.full((n, len(MILESTONES)), -1, dtype=torch.int32, device=dev)
-    expanded_total = torch.zeros((), dtype=torch.int64, device=dev)
+    expanded_sum = torch.zeros(n, dtype=torch.int64, device=dev)
     t = 0
     while t < max_moves:
         actions, _, expanded = ops.beam_get_action(env.boards, beam_width, search_depth, None, early_game_threshold,
                                                    mid_game_threshold, seed, t, game_id_base, fixed_down,
                                                    want_expanded=True)
-        _, _, done, _ = env.step(actions)
-        flags = env.flags
-        maxcode = flags >> L.FLAG_MAXCODE_SHIFT
-        valid = (flags & L.FLAG_VALID).bool()
-        hit = alive[:, None] & (ms_move < 0) & (maxcode[:, None] >= ms_codes[None, :])     # evaluate_beam_search.py:60-64
-        ms_move = torch.where(hit, torch.full_like(ms_move, t), ms_move)
-        valid_cnt += (alive & valid).int()
-        invalid_cnt += (alive & ~valid).int()
-        expanded_total += (expanded.long() * alive.long()).sum()
-        moves += alive.int()
-        alive = alive & ~done
+        env.step(actions)
+        # evaluate_beam_search.py:42-64 for every game, one kernel
+        ops.track_episodes(env.flags, alive, moves, valid_cnt, invalid_cnt, ms_move, t, expanded, expanded_sum)
         t += 1
         if t % check_every == 0 and not bool(alive.any()):
             break
+    expanded_total = expanded_sum.sum()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t_start
 

@@ -99,6 +99,26 @@ def obs(boards, out=None):
     return out
 
 
+def track_episodes(flags, alive, moves, valid_cnt, invalid_cnt, milestone_move, move_index, expanded=None,
+                   expanded_sum=None):
+    """One-kernel bookkeeping of the evaluation loop (reference evaluate_beam_search.py:42-64); all tensors are
+    updated in place. alive uint8 (n,), moves/valid_cnt/invalid_cnt int32 (n,), milestone_move int32 (n,8)."""
+    n = flags.shape[0]
+    L.require_device_tensor(flags, torch.uint8, None, "flags")
+    L.require_device_tensor(alive, torch.uint8, None, "alive")
+    for name, t in (("moves", moves), ("valid_cnt", valid_cnt), ("invalid_cnt", invalid_cnt)):
+        L.require_device_tensor(t, torch.int32, None, name)
+    L.require_device_tensor(milestone_move, torch.int32, (8,), "milestone_move")
+    if expanded is not None:
+        L.require_device_tensor(expanded, torch.int32, None, "expanded")
+        L.require_device_tensor(expanded_sum, torch.int64, None, "expanded_sum")
+    L.check(L.lib().g2048_track_episodes(flags.data_ptr(), expanded.data_ptr() if expanded is not None else None,
+                                         alive.data_ptr(), moves.data_ptr(), valid_cnt.data_ptr(), invalid_cnt.data_ptr(),
+                                         milestone_move.data_ptr(),
+                                         expanded_sum.data_ptr() if expanded is not None else None,
+                                         int(move_index), n, L.stream_ptr(flags.device)))
+
+
 def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, actions=None, prob=None):
     """Masked categorical sampling (PPOAgent.get_action, agents/ppo_agent.py:211-221) for every env in one kernel.
     probs float32 (n,4); mask4 uint8 (n,) or None. Returns (actions uint8 (n,), prob float32 (n,))."""

@@ -114,6 +114,15 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
                           uint32_t opts, void *stream);
 
+/* Per-move bookkeeping of the reference's evaluation loops (evaluate_beam_search.py:42-64, run_evaluation.py:56-69)
+ * for n games after a g2048_step: for games still alive, milestone_move_inout[i][k] (k = 0..7 for tiles 64..8192,
+ * -1 = not reached yet) records move_index the first time the max tile reaches it, the valid / invalid / total move
+ * counters advance, expanded_or_null[i] is added to expanded_sum, and the game leaves `alive` when its DONE flag is
+ * set. Games not alive are untouched. */
+int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+                         int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
+                         unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream);
+
 /* The masked sampling of PPOAgent.get_action (agents/ppo_agent.py:211-221) for n envs: probs is float32 [n][4]
  * (the actor's softmax output), mask4 as g2048_valid_moves writes it (NULL = all valid). The action is drawn from
  * weights p_a + 1e-10 over the valid actions (what Categorical(logits = log(p + 1e-10) + mask) samples) by inverse
