@@ -75,6 +75,18 @@ def stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def call(device, fn, *args):
+    """Invoke a C-ABI entry point with `device` as the calling thread's current HIP device (a launch goes to the
+    current device, which need not be the tensors' device in a one-process multi-GPU program) and check its status."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() == idx:
+        rc = fn(*args)
+    else:
+        with torch.cuda.device(idx):
+            rc = fn(*args)
+    check(rc)
+
+
 def require_device_tensor(t, dtype, shape_tail=None, name="tensor"):
     if not isinstance(t, torch.Tensor):
         raise TypeError("g2048: %s must be a torch.Tensor" % name)

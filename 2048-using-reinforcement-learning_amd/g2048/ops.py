@@ -41,9 +41,9 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) | ((int(tune) & 3) << 8)
-    L.check(L.lib().g2048_step(boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+    L.call(dev, L.lib().g2048_step, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
                                reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base),
-                               n, opts, L.stream_ptr(dev)))
+                               n, opts, L.stream_ptr(dev))
     return out, reward, flags
 
 
@@ -56,8 +56,8 @@ def reset(n, seed, epoch=0, id_base=0, device="cuda", boards=None, scores=None):
         scores = torch.empty(n, dtype=torch.int32, device=dev)
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     _require_scores(scores)
-    L.check(L.lib().g2048_reset(boards.data_ptr(), scores.data_ptr(), L.u64(seed), L.u64(epoch), L.u64(id_base),
-                                boards.shape[0], L.stream_ptr(dev)))
+    L.call(dev, L.lib().g2048_reset, boards.data_ptr(), scores.data_ptr(), L.u64(seed), L.u64(epoch), L.u64(id_base),
+                                boards.shape[0], L.stream_ptr(dev))
     return boards, scores
 
 
@@ -68,8 +68,8 @@ def valid_moves(boards, agent_semantics=False, out=None):
     if out is None:
         out = torch.empty(boards.shape[0], dtype=torch.uint8, device=boards.device)
     L.require_device_tensor(out, torch.uint8, None, "out")
-    L.check(L.lib().g2048_valid_moves(boards.data_ptr(), out.data_ptr(), boards.shape[0],
-                                      L.VALID_AGENT if agent_semantics else L.VALID_ENV, L.stream_ptr(boards.device)))
+    L.call(boards.device, L.lib().g2048_valid_moves, boards.data_ptr(), out.data_ptr(), boards.shape[0],
+                                      L.VALID_AGENT if agent_semantics else L.VALID_ENV, L.stream_ptr(boards.device))
     return out
 
 
@@ -84,8 +84,8 @@ def evaluate(boards, kind, phase=None, out=None):
     if out is None:
         out = torch.empty(boards.shape[0], dtype=torch.float64, device=boards.device)
     L.require_device_tensor(out, torch.float64, None, "out")
-    L.check(L.lib().g2048_eval(boards.data_ptr(), int(kind), phase.data_ptr() if phase is not None else None,
-                               out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    L.call(boards.device, L.lib().g2048_eval, boards.data_ptr(), int(kind), phase.data_ptr() if phase is not None else None,
+                               out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device))
     return out
 
 
@@ -95,7 +95,7 @@ def obs(boards, out=None):
     if out is None:
         out = torch.empty((boards.shape[0], 16), dtype=torch.float32, device=boards.device)
     L.require_device_tensor(out, torch.float32, (16,), "out")
-    L.check(L.lib().g2048_obs_f32(boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    L.call(boards.device, L.lib().g2048_obs_f32, boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device))
     return out
 
 
@@ -112,11 +112,11 @@ def track_episodes(flags, alive, moves, valid_cnt, invalid_cnt, milestone_move, 
     if expanded is not None:
         L.require_device_tensor(expanded, torch.int32, None, "expanded")
         L.require_device_tensor(expanded_sum, torch.int64, None, "expanded_sum")
-    L.check(L.lib().g2048_track_episodes(flags.data_ptr(), expanded.data_ptr() if expanded is not None else None,
+    L.call(flags.device, L.lib().g2048_track_episodes, flags.data_ptr(), expanded.data_ptr() if expanded is not None else None,
                                          alive.data_ptr(), moves.data_ptr(), valid_cnt.data_ptr(), invalid_cnt.data_ptr(),
                                          milestone_move.data_ptr(),
                                          expanded_sum.data_ptr() if expanded is not None else None,
-                                         int(move_index), n, L.stream_ptr(flags.device)))
+                                         int(move_index), n, L.stream_ptr(flags.device))
 
 
 def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, actions=None, prob=None):
@@ -133,9 +133,9 @@ def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, acti
         prob = torch.empty(n, dtype=torch.float32, device=dev)
     L.require_device_tensor(actions, torch.uint8, None, "actions")
     L.require_device_tensor(prob, torch.float32, None, "prob")
-    L.check(L.lib().g2048_sample_actions(probs.data_ptr(), mask4.data_ptr() if mask4 is not None else None,
+    L.call(dev, L.lib().g2048_sample_actions, probs.data_ptr(), mask4.data_ptr() if mask4 is not None else None,
                                          actions.data_ptr(), prob.data_ptr(), L.u64(seed), L.u64(step_index),
-                                         L.u64(id_base), n, L.stream_ptr(dev)))
+                                         L.u64(id_base), n, L.stream_ptr(dev))
     return actions, prob
 
 
@@ -155,10 +155,10 @@ def simulate_move(boards, actions, highest_code=None):
     reward = torch.empty((n, 32), dtype=torch.float64, device=dev)
     done = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     count = torch.empty(n, dtype=torch.uint8, device=dev)
-    L.check(L.lib().g2048_simulate_move(boards.data_ptr(), actions.data_ptr(),
+    L.call(dev, L.lib().g2048_simulate_move, boards.data_ptr(), actions.data_ptr(),
                                         highest_code.data_ptr() if highest_code is not None else None,
                                         succ.data_ptr(), reward.data_ptr(), done.data_ptr(), count.data_ptr(), n,
-                                        L.stream_ptr(dev)))
+                                        L.stream_ptr(dev))
     return succ, reward, done.bool(), count
 
 
@@ -167,7 +167,7 @@ def pack(tiles, out=None):
     L.require_device_tensor(tiles, torch.int32, (16,), "tiles")
     if out is None:
         out = torch.empty((tiles.shape[0], 16), dtype=torch.uint8, device=tiles.device)
-    L.check(L.lib().g2048_pack_i32(tiles.data_ptr(), out.data_ptr(), tiles.shape[0], L.stream_ptr(tiles.device)))
+    L.call(tiles.device, L.lib().g2048_pack_i32, tiles.data_ptr(), out.data_ptr(), tiles.shape[0], L.stream_ptr(tiles.device))
     return out
 
 
@@ -175,7 +175,7 @@ def unpack(boards, out=None):
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     if out is None:
         out = torch.empty((boards.shape[0], 16), dtype=torch.int32, device=boards.device)
-    L.check(L.lib().g2048_unpack_i32(boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+    L.call(boards.device, L.lib().g2048_unpack_i32, boards.data_ptr(), out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device))
     return out
 
 
@@ -184,8 +184,8 @@ def synth_boards(n, seed=0x2048, id_base=0, p_empty=0.30, max_code=11, device="c
     if out is None:
         out = torch.empty((n, 16), dtype=torch.uint8, device=device)
     L.require_device_tensor(out, torch.uint8, (16,), "out")
-    L.check(L.lib().g2048_synth_boards(out.data_ptr(), L.u64(seed), L.u64(id_base), out.shape[0],
-                                       int(round(p_empty * 65536)), int(max_code), L.stream_ptr(out.device)))
+    L.call(out.device, L.lib().g2048_synth_boards, out.data_ptr(), L.u64(seed), L.u64(id_base), out.shape[0],
+           int(round(p_empty * 65536)), int(max_code), L.stream_ptr(out.device))
     return out
 
 
@@ -193,8 +193,8 @@ def synth_actions(n, seed=0x2048, step_index=0, id_base=0, device="cuda", out=No
     if out is None:
         out = torch.empty(n, dtype=torch.uint8, device=device)
     L.require_device_tensor(out, torch.uint8, None, "out")
-    L.check(L.lib().g2048_synth_actions(out.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), out.shape[0],
-                                        L.stream_ptr(out.device)))
+    L.call(out.device, L.lib().g2048_synth_actions, out.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), out.shape[0],
+                                        L.stream_ptr(out.device))
     return out
 
 
@@ -203,10 +203,10 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     if out is None:
         out = torch.zeros(24, dtype=torch.int64, device=boards.device)
-    L.check(L.lib().g2048_metrics(boards.data_ptr(), scores.data_ptr() if scores is not None else None,
+    L.call(boards.device, L.lib().g2048_metrics, boards.data_ptr(), scores.data_ptr() if scores is not None else None,
                                   flags.data_ptr() if flags is not None else None,
                                   expanded.data_ptr() if expanded is not None else None,
-                                  out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device)))
+                                  out.data_ptr(), boards.shape[0], L.stream_ptr(boards.device))
     return out
 
 
@@ -226,16 +226,16 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     actions = torch.empty(n, dtype=torch.uint8, device=dev)
     probs = torch.empty(n, dtype=torch.float32, device=dev)
     expanded = torch.empty(n, dtype=torch.int32, device=dev) if want_expanded else None
-    L.check(L.lib().g2048_beam_get_action(roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None,
+    L.call(dev, L.lib().g2048_beam_get_action, roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None,
                                           actions.data_ptr(), probs.data_ptr(),
                                           expanded.data_ptr() if expanded is not None else None,
                                           int(width), int(depth), int(early_threshold), int(mid_threshold),
                                           L.u64(seed), L.u64(step_index), L.u64(game_id_base), n,
-                                          L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev)))
+                                          L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev))
     return (actions, probs, expanded) if want_expanded else (actions, probs)
 
 
 def selftest(device="cuda"):
     r = torch.full((1,), 0xFFFF, dtype=torch.int32, device=device)
-    L.check(L.lib().g2048_selftest(r.data_ptr(), L.stream_ptr(r.device)))
+    L.call(r.device, L.lib().g2048_selftest, r.data_ptr(), L.stream_ptr(r.device))
     return int(r.item())
