@@ -42,9 +42,9 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                                                  uint64_t id_base, bool fixed_down)
 {
     __shared__ uint4 s_board[kMaxWidth];                        // the beam, rank order
-    __shared__ uint32_t s_root[kMaxWidth];                      // root action of each beam entry
+    __shared__ uint32_t s_root[kMaxWidth];                      // root action | (max code << 8) of each beam entry
     __shared__ uint4 s_cboard[64 * PASSES];                     // moved (pre-spawn) boards of the VALID children,
-    __shared__ uint32_t s_croot[64 * PASSES];                   //   compacted in generation order, + their root action
+    __shared__ uint32_t s_croot[64 * PASSES];                   //   compacted in generation order, + root action | parent max << 8
     __shared__ __align__(16) double s_score[64 * PASSES + 2];   // f64 scores (levels 1..3) or, reinterpreted, u32 keys
 
     const uint32_t lane = threadIdx.x;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
         return;
     }
     // :96-106 -- phase and depth are fixed from the ROOT board
-    const uint32_t phase = phase_of(max_code(root), early_thr, mid_thr);
+    const uint32_t root_max = max_code(root);
+    const uint32_t phase = phase_of(root_max, early_thr, mid_thr);
     const uint32_t root_empty = count_empty(root);
     int actual_depth;
     if (root_empty <= 4u) actual_depth = min(depth + 5, 25);
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                 bool enabled = slot < nslots;
                 const uint32_t a = (uint32_t)slot & 3u;
                 Board P = root;
-                uint32_t ra = a;
+                uint32_t ra = a | (root_max << 8);
                 if (level == 0) {
                     enabled = enabled && ((mask >> a) & 1u);
                 } else if (enabled) {
@@ -128,16 +129,18 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
         // more than 64 children are valid)
         Board child[PASSES];
         double score[PASSES];
-        uint32_t ikey[PASSES];
+        uint32_t ikey[PASSES], cmaxv[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            score[p] = 0.0; ikey[p] = 0u; child[p] = root;
+            score[p] = 0.0; ikey[p] = 0u; cmaxv[p] = 0u; child[p] = root;
             if ((uint32_t)(p * 64) < total_valid) {                              // wave-uniform
                 const uint32_t ci = (uint32_t)(p * 64) + lane;
                 const bool live = ci < total_valid;
                 const uint4 cv = s_cboard[live ? ci : 0u];
                 Board c = {{cv.x, cv.y, cv.z, cv.w}};
-                const bool consume = live && count_empty(c) != 0u;               // :262-263
+                const uint32_t pmax = s_croot[live ? ci : 0u] >> 8;
+                const uint32_t n_moved = count_empty(c);
+                const bool consume = live && n_moved != 0u;                      // :262-263
                 const unsigned long long bc = __ballot(consume);
                 const uint32_t j = draws + prefix_count(bc);
                 draws += (uint32_t)__popcll(bc);
@@ -150,11 +153,17 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                 // :122 / :158-161. _fast_evaluate is integer-valued (< 2^19), so on those levels the sort key
                 // (score desc, generation order asc) is the single unique integer score * 256 + (255 - index);
                 // the f64 path is only needed for _evaluate_state (levels 1..3).
+                // what the evaluators need is already known: the empty count (one fewer after a spawn) and the
+                // max code -- a move raises the parent's max by at most one, exactly when some cell now holds
+                // parent max + 1 (two max tiles merged, or a 2/4 spawned onto a board whose max was lower)
+                const uint32_t n_child = n_moved - (consume ? 1u : 0u);
+                const uint32_t cmax = pmax + (has_code(c, pmax + 1u) ? 1u : 0u);
+                cmaxv[p] = cmax;
                 if (fast) {
-                    ikey[p] = live ? (eval_fast_u32(c) << 8) + (255u - ci) : 0u;
+                    ikey[p] = live ? (eval_fast_u32_known(c, n_child, cmax) << 8) + (255u - ci) : 0u;
                     reinterpret_cast<uint32_t *>(s_score)[ci] = ikey[p];         // ci < 64 * PASSES always
                 } else {
-                    score[p] = eval_full(c, phase);
+                    score[p] = eval_full_known(c, phase, n_child, cmax);
                     s_score[ci] = live ? score[p] : -INFINITY;
                 }
                 child[p] = c;
@@ -191,14 +200,14 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
             const uint32_t ci = (uint32_t)(p * 64) + lane;
             if (ci < total_valid && rank[p] < (uint32_t)width) {                  // :132 / :175
                 s_board[rank[p]] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
-                s_root[rank[p]] = s_croot[ci];
+                s_root[rank[p]] = (s_croot[ci] & 0xffu) | (cmaxv[p] << 8);
             }
         }
         nb = (int)min(total_valid, (uint32_t)width);
         __syncthreads();
     }
     if (lane == 0) {                                                            // :178-181
-        action_out[g] = (uint8_t)s_root[0];
+        action_out[g] = (uint8_t)(s_root[0] & 0xffu);
         prob_out[g] = 1.0f;
         if (expanded_out) expanded_out[g] = expanded;
     }

@@ -497,10 +497,12 @@ G2048_HD SimOut simulate_successor(const Board &state, const Board &moved, uint3
 // ------------------------------------------------------------- heuristics -----
 G2048_HD uint32_t pair_count(const Board &b)      // adjacent equal non-zero pairs, h + v
 {
-    uint32_t cnt = popc(eqnzflag(b.w[0], b.w[1])) + popc(eqnzflag(b.w[1], b.w[2])) + popc(eqnzflag(b.w[2], b.w[3]));
+    // seven flag words (bit 7 of a byte each); shifted right by 0..6 they occupy seven different bits of the
+    // byte, so one OR-reduction and one popcount count them all
+    uint32_t w = eqnzflag(b.w[0], b.w[1]) | (eqnzflag(b.w[1], b.w[2]) >> 1) | (eqnzflag(b.w[2], b.w[3]) >> 2);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cnt += popc(eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u);
-    return cnt;
+    for (int r = 0; r < 4; ++r) w |= (eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u) >> (3 + r);
+    return popc(w);
 }
 
 G2048_HD uint32_t max_corner_code(const Board &b)
@@ -521,6 +523,20 @@ G2048_HD uint32_t eval_fast_u32(const Board &b)
 
 G2048_HD double eval_fast(const Board &b) { return (double)eval_fast_u32(b); }
 
+// the same with the empty count and the max code supplied by a caller that already knows them (beam kernel)
+G2048_HD uint32_t eval_fast_u32_known(const Board &b, uint32_t n_empty, uint32_t maxcode)
+{
+    const uint32_t cc = max_corner_code(b);
+    return n_empty * 10u + maxcode * 2u + (cc ? (2u << cc) : 0u) + pair_count(b) * 2u;
+}
+
+// true iff some cell holds `code` (code >= 1)
+G2048_HD bool has_code(const Board &b, uint32_t code)
+{
+    const uint32_t c = code * 0x01010101u;
+    return (zflag(b.w[0] ^ c) | zflag(b.w[1] ^ c) | zflag(b.w[2] ^ c) | zflag(b.w[3] ^ c)) != 0u;
+}
+
 // sum of codes over adjacent equal non-zero pairs (_calculate_merge_potential, :387-403)
 G2048_HD uint32_t merge_potential(const Board &b)
 {
@@ -540,16 +556,18 @@ G2048_HD uint32_t merge_potential(const Board &b)
 
 // BeamSearchAgent._evaluate_state (agents/beam_search_agent.py:316-373), phase 0/1/2 =
 // early/mid/late (:271-278), f64, same operation order. snake_patterns[0] (:37-42).
-G2048_HD double eval_full(const Board &b, uint32_t phase)
+G2048_HD double eval_full_known(const Board &b, uint32_t phase, uint32_t e, uint32_t mc);
+
+G2048_HD double eval_full(const Board &b, uint32_t phase) { return eval_full_known(b, phase, count_empty(b), max_code(b)); }
+
+G2048_HD double eval_full_known(const Board &b, uint32_t phase, uint32_t e, uint32_t mc)
 {
     const double we = phase == 0 ? 15.0 : phase == 1 ? 10.0 : 8.0;
     const double wm = phase == 0 ? 1.0 : phase == 1 ? 1.5 : 2.0;
     const double wc = phase == 0 ? 2.0 : phase == 1 ? 2.5 : 3.0;
     const double wg = phase == 0 ? 2.0 : phase == 1 ? 1.5 : 1.0;
-    const uint32_t e = count_empty(b);
     double empty_score = (double)e * we;
     if (e <= 2u) empty_score -= 10.0;
-    const uint32_t mc = max_code(b);
     double max_score = (double)mc * wm;
     if (mc >= 9u) max_score *= 1.2;
     if (mc >= 10u) max_score *= 1.5;
