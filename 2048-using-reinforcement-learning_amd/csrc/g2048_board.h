@@ -262,7 +262,7 @@ G2048_HD bool game_over(const Board &b) { return valid_mask_env(b) == 0u; }
 // order gets a 2 (code 1) or a 4 (code 2). h is one 32-bit draw:
 // idx = ((h >> 16) * n_empty) >> 16, four iff (h & 0xffff) >= 58982.
 // No-op on a full board. Returns n_empty before the spawn.
-G2048_HD uint32_t spawn(Board &b, uint32_t h)
+G2048_HD uint32_t spawn(Board &b, uint32_t h, bool enable = true)
 {
     const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
     const uint32_t c0 = popc(z0), c1 = c0 + popc(z1), c2 = c1 + popc(z2), n = c2 + popc(z3);
@@ -274,7 +274,7 @@ G2048_HD uint32_t spawn(Board &b, uint32_t h)
     z &= z - (k > 1 ? 1u : 0u);
     z &= z - (k > 2 ? 1u : 0u);
     const uint32_t bit = z & (0u - z);  // 0x80 << 8c of the chosen cell (0 when the board is full)
-    const uint32_t add = (n == 0u) ? 0u : bit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
+    const uint32_t add = (n == 0u || !enable) ? 0u : bit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
     b.w[0] |= row == 0 ? add : 0u; b.w[1] |= row == 1 ? add : 0u;
     b.w[2] |= row == 2 ? add : 0u; b.w[3] |= row == 3 ? add : 0u;
     return n;
@@ -376,6 +376,31 @@ G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain,
     return reward_env_from((double)gain / 4.0, cur, st, valid, empty_before, empty_after);
 }
 
+// The same value with the first three terms folded: gain/4, -2.0 for an invalid move and (after - before) * 0.5 are
+// all exact multiples of 0.25 of small magnitude, so the reference's three roundings are no-ops and the partial
+// sum equals (gain - 8*[invalid] + 2*(after - before)) * 0.25 exactly -- one conversion and one multiply.
+G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
+                                  uint32_t empty_before, uint32_t empty_after)
+{
+    const int32_t q = (int32_t)gain - (valid ? 0 : 8) + 2 * ((int32_t)empty_after - (int32_t)empty_before);
+    double r = (double)q * 0.25;
+    r += ((double)st.edge / (double)st.total) * 1.0;
+    if (empty_after <= 2u) r -= 2.0;
+    const uint32_t n0 = nzflag(cur.w[0]), n1 = nzflag(cur.w[1]), n2 = nzflag(cur.w[2]), n3 = nzflag(cur.w[3]);
+    const uint32_t v01 = geflag(cur.w[1], cur.w[0]) & n0 & n1;
+    const uint32_t v12 = geflag(cur.w[2], cur.w[1]) & n1 & n2;
+    const uint32_t v23 = geflag(cur.w[3], cur.w[2]) & n2 & n3;
+    const uint32_t colcnt = (v01 >> 7) + (v12 >> 7) + (v23 >> 7);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = cur.w[i], n = i == 0 ? n0 : i == 1 ? n1 : i == 2 ? n2 : n3;
+        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8) & 0x00808080u;
+        const uint32_t c = popc(h) + ((colcnt >> (8 * i)) & 0xffu);
+        r += (double)c * 0.1;
+    }
+    return r;
+}
+
 // done <=> no direction changes the board (environment/game_2048.py:279-288): a full board
 // without equal neighbours, or (degenerate) an all-empty board. pair_count is defined below.
 G2048_HD uint32_t pair_count(const Board &b);
@@ -398,18 +423,13 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
     Board cur = move_env(prev, action, o.gain, merges);
     const bool valid = !same(cur, prev);
     uint32_t empty_mid;                 // empties of the moved board, before the spawn
-    {
-        Board spawned = cur;
-        empty_mid = spawn(spawned, h);
-        cur.w[0] = valid ? spawned.w[0] : cur.w[0]; cur.w[1] = valid ? spawned.w[1] : cur.w[1];
-        cur.w[2] = valid ? spawned.w[2] : cur.w[2]; cur.w[3] = valid ? spawned.w[3] : cur.w[3];
-    }
+    empty_mid = spawn(cur, h, valid);
     // a slide moves tiles and every merge frees one cell; a valid move then fills one (a valid move always
     // leaves an empty cell: either a tile slid into a gap or a merge freed a cell)
     const uint32_t empty_before = empty_mid - merges;
     const uint32_t empty_after = empty_mid - (valid ? 1u : 0u);
     const TileStats st = tile_stats(cur, empty_after);
-    o.reward = reward_env(cur, st, o.gain, valid, empty_before, empty_after);
+    o.reward = reward_env_folded(cur, st, o.gain, valid, empty_before, empty_after);
     const bool done = game_over_counted(cur, empty_after);
     const uint32_t maxcode = 31u - (uint32_t)__builtin_clz(st.orbits | 1u);
     o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);

@@ -69,36 +69,47 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                                                      uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
                                                      uint64_t id_base, size_t n)
 {
-    const size_t base = (size_t)blockIdx.x * (BLOCK * B) + threadIdx.x;
+    // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
+    const size_t block0 = (size_t)blockIdx.x * (BLOCK * B);
+    const uint4 *bin = boards_in + block0;
+    uint4 *bout = boards_out + block0;
+    const uint8_t *act = actions + block0;
+    uint32_t *scp = score + block0;
+    uint8_t *flp = flags_out + block0;
+    float *rw32 = static_cast<float *>(reward_out) + block0;
+    double *rw64 = static_cast<double *>(reward_out) + block0;
+    const bool full = block0 + (size_t)(BLOCK * B) <= n;          // wave-uniform: every lane of the block is in range
+    const uint32_t lim = full ? (uint32_t)(BLOCK * B) : (uint32_t)(n - block0);
     Board prev[B];
     uint32_t action[B], sc[B];
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        const size_t i = base + (size_t)k * BLOCK;
-        if (i < n) {
-            prev[k] = load_board(boards_in, i);
-            action[k] = actions[i];
-            sc[k] = score[i];
+        const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
+        if (full || j < lim) {
+            prev[k] = load_board(bin, j);
+            action[k] = act[j];
+            sc[k] = scp[j];
         }
     }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        const size_t i = base + (size_t)k * BLOCK;
-        if (i >= n) break;
-        const StepOut o = step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id_base + i, 0u));
+        const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
+        if (!(full || j < lim)) break;
+        const uint64_t id = id_base + block0 + j;
+        const StepOut o = step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id, 0u));
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
         if (AUTO_RESET) {
             if (o.flags & G2048_FLAG_DONE) {
-                cur = fresh_board(rng_draw(e0, e1, id_base + i, 0u), rng_draw(e0, e1, id_base + i, 1u));
+                cur = fresh_board(rng_draw(e0, e1, id, 0u), rng_draw(e0, e1, id, 1u));
                 s = 0u;
             }
         }
-        store_board(boards_out, i, cur);
-        score[i] = s;
-        if (REWARD_F64) static_cast<double *>(reward_out)[i] = o.reward;
-        else static_cast<float *>(reward_out)[i] = (float)o.reward;
-        flags_out[i] = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
+        store_board(bout, j, cur);
+        scp[j] = s;
+        if (REWARD_F64) rw64[j] = o.reward;
+        else rw32[j] = (float)o.reward;
+        flp[j] = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
     }
 }
 

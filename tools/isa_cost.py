@@ -10,7 +10,7 @@ FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
         "v_lshrrev_b32", "v_add_co_u32", "v_addc_co_u32"}
 s = open(sys.argv[1]).read()
 flt = sys.argv[2]
-for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)\n\ts_endpgm', s, re.S | re.M):
+for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)\n\.Lfunc_end', s, re.S | re.M):
     name, body = m.group(1), m.group(2)
     if flt not in name:
         continue

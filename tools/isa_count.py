@@ -7,7 +7,7 @@ import sys
 
 s = open(sys.argv[1]).read()
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)\n\ts_endpgm', s, re.S | re.M):
+for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)\n\.Lfunc_end', s, re.S | re.M):
     name, body = m.group(1), m.group(2)
     if flt not in name:
         continue
