@@ -56,14 +56,7 @@ G2048_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 #endif
 }
 
-G2048_HD uint32_t popc(uint32_t x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_popcount(x);
-#else
-    return (uint32_t)__builtin_popcount(x);
-#endif
-}
+G2048_HD uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }      // v_bcnt_u32_b32
 
 // sum over the 4 bytes of a[i]*b[i] + c  (v_dot4_u32_u8)
 G2048_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)

@@ -38,8 +38,7 @@ extern "C" {
 enum {
     G2048_OK = 0,
     G2048_ERR_ARG = -1,        /* bad argument (null pointer, misaligned board array, bad enum) */
-    G2048_ERR_HIP = -2,        /* HIP runtime error (no device, launch failure) */
-    G2048_ERR_WORKSPACE = -3   /* workspace too small */
+    G2048_ERR_HIP = -2         /* HIP runtime error (no device, launch failure) */
 };
 
 /* flags_out byte of g2048_step */
