@@ -77,37 +77,45 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     uint32_t draws = 0, expanded = 0;
 
     for (int level = 0; level == 0 || level < actual_depth; ++level) {
-        const int nslots = level == 0 ? 4 : 4 * nb;
         const bool fast = level == 0 || level > 3;             // :122, :139
-        // ---- stage A: one agent move per (parent, action) slot; valid children are compacted into LDS in
-        // generation order (parent rank, then action), which is also the order the reference draws in.
+        // ---- stage A: lane 2p + axis makes BOTH moves of one axis of parent p (axis 0: LEFT, RIGHT; axis 1: UP,
+        // DOWN), so 2 * beam <= 64 lanes cover all four moves of every parent in one round. Valid children are
+        // compacted into LDS in generation order (parent rank, then action 0..3) = the order the reference draws in.
         uint32_t total_valid = 0;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            if (p * 64 < nslots) {                                               // wave-uniform
-                const int slot = p * 64 + (int)lane;
-                bool enabled = slot < nslots;
-                const uint32_t a = (uint32_t)slot & 3u;
-                Board P = root;
-                uint32_t ra = a | (root_max << 8);
-                if (level == 0) {
-                    enabled = enabled && ((mask >> a) & 1u);
-                } else if (enabled) {
-                    const uint4 pv = s_board[slot >> 2];
-                    P = Board{{pv.x, pv.y, pv.z, pv.w}};
-                    ra = s_root[slot >> 2];
-                }
-                uint32_t gain;
-                const Board c = move_agent(P, a, gain, fixed_down);              // :115 / :152
-                const bool v = enabled && !same(c, P);
-                const unsigned long long bv = __ballot(v);
-                const uint32_t ci = total_valid + prefix_count(bv);
-                total_valid += (uint32_t)__popcll(bv);
-                if (v) {
-                    s_cboard[ci] = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
-                    s_croot[ci] = ra;
-                }
+        {
+            const uint32_t par = lane >> 1;
+            const bool vertical = (lane & 1u) != 0u;
+            const bool on = (int)par < (level == 0 ? 1 : nb);
+            Board P = root;
+            uint32_t ra_f = (vertical ? 1u : 0u) | (root_max << 8), ra_r = (vertical ? 3u : 2u) | (root_max << 8);
+            bool en_f = on, en_r = on;
+            if (level == 0) {
+                en_f = on && ((mask >> (vertical ? 1 : 0)) & 1u);
+                en_r = on && ((mask >> (vertical ? 3 : 2)) & 1u);
+            } else if (on) {
+                const uint4 pv = s_board[par];
+                P = Board{{pv.x, pv.y, pv.z, pv.w}};
+                ra_f = ra_r = s_root[par];
             }
+            Board cf, cr;
+            move_axis(P, vertical, cf, cr);                                      // :115 / :152
+            if (!fixed_down) {                                                   // the agent's DOWN = rot180(true DOWN)
+                const Board q = rot180(cr);
+                cr.w[0] = vertical ? q.w[0] : cr.w[0]; cr.w[1] = vertical ? q.w[1] : cr.w[1];
+                cr.w[2] = vertical ? q.w[2] : cr.w[2]; cr.w[3] = vertical ? q.w[3] : cr.w[3];
+            }
+            const bool vf = en_f && !same(cf, P), vr = en_r && !same(cr, P);
+            const unsigned long long bf = __ballot(vf), br = __ballot(vr);
+            const uint32_t before = prefix_count(bf) + prefix_count(br);         // valid children of lower lanes
+            // partner lane (same parent, other axis) through a DPP quad swap
+            const uint32_t mine = (vf ? 1u : 0u) | (vr ? 2u : 0u);
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+            // order inside a parent: LEFT(h,f) UP(v,f) RIGHT(h,r) DOWN(v,r)
+            const uint32_t idx_f = vertical ? before - ((other >> 1) & 1u) : before;
+            const uint32_t idx_r = vertical ? before + (mine & 1u) : before + (mine & 1u) + (other & 1u);
+            total_valid = (uint32_t)__popcll(bf) + (uint32_t)__popcll(br);
+            if (vf) { s_cboard[idx_f] = make_uint4(cf.w[0], cf.w[1], cf.w[2], cf.w[3]); s_croot[idx_f] = ra_f; }
+            if (vr) { s_cboard[idx_r] = make_uint4(cr.w[0], cr.w[1], cr.w[2], cr.w[3]); s_croot[idx_r] = ra_r; }
         }
         expanded += total_valid;
         if (total_valid == 0u) {
