@@ -43,7 +43,14 @@ void hs_valid(const uint8_t *in, int agent, uint8_t *mask, size_t n)
 
 void hs_spawn(const uint8_t *in, const uint32_t *h, uint8_t *out, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) { Board b = ld(in + 16 * i); spawn(b, h[i]); st(out + 16 * i, b); }
+    for (size_t i = 0; i < n; ++i) {
+        Board b = ld(in + 16 * i), c = b;
+        uint32_t za[4], zb[4];
+        const uint32_t na = spawn(b, h[i], true, za), nb = spawn_prefix(c, h[i], true, zb);
+        // the two formulations must agree on everything; a disagreement poisons the output so the test fails
+        if (!same(b, c) || na != nb || memcmp(za, zb, sizeof za) != 0) b.w[0] = 0xffffffffu;
+        st(out + 16 * i, b);
+    }
 }
 
 void hs_step(const uint8_t *in, const uint8_t *actions, const uint32_t *h, uint8_t *out, uint32_t *score,
