@@ -279,6 +279,33 @@ int g2048o_simulate_move(const int32_t state[16], int action, int32_t highest_ti
  * fliplr(board.T) (:210); post-transform is board.T then fliplr (:252-253),
  * which is NOT the inverse -- the returned DOWN board is rot180 of the true
  * result. Reproduced on purpose.                                */
+/* fixed_down != 0 is NOT the reference: it replaces the quirky post-transform of DOWN by the true inverse (the
+ * product's G2048_BEAM_FIXED_DOWN option). Everything pinned by the goldens runs with fixed_down == 0.        */
+static void agent_move_opt(const int32_t in[16], int action, int32_t out[16], int32_t *score, int *valid, int fixed_down)
+{
+    if (fixed_down && action == 3) {
+        int32_t w[16]; memcpy(w, in, sizeof w);
+        int32_t gain = 0;
+        g2048o_env_move(w, 3, &gain);
+        memcpy(out, w, sizeof w);
+        if (score) *score = gain;
+        if (valid) *valid = memcmp(in, w, sizeof w) != 0;
+        return;
+    }
+    g2048o_agent_move(in, action, out, score, valid);
+}
+
+static int agent_valid_mask_opt(const int32_t b[16], int fixed_down)
+{
+    int mask = 0;
+    for (int a = 0; a < 4; ++a) {
+        int32_t t[16]; int v;
+        agent_move_opt(b, a, t, NULL, &v, fixed_down);
+        if (v) mask |= 1 << a;
+    }
+    return mask;
+}
+
 void g2048o_agent_move(const int32_t in[16], int action, int32_t out[16], int32_t *score, int *valid)
 {
     int32_t w[16]; memcpy(w, in, sizeof w);
@@ -406,6 +433,11 @@ static void stable_sort_desc(cand_t *c, int n)
 #define G2048O_MAX_WIDTH 256
 
 /* agents/beam_search_agent.py:71-181 (get_action).                          */
+static int beam_impl(const int32_t root[16], int valid_mask4, int width, int depth, int32_t early_thr, int32_t mid_thr,
+                     const uint32_t *draws, size_t n_draws, uint64_t seed, uint64_t step_index, uint64_t game_id,
+                     int *action_out, float *prob_out, uint32_t *n_consumed, uint32_t *n_expanded,
+                     double *trace_scores, int32_t *trace_counts, int trace_levels, int fixed_down);
+
 int g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
                            int width, int depth, int32_t early_thr, int32_t mid_thr,
                            const uint32_t *draws, size_t n_draws,
@@ -414,6 +446,15 @@ int g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
                            uint32_t *n_expanded,
                            double *trace_scores, int32_t *trace_counts, int trace_levels)
 {
+    return beam_impl(root, valid_mask4, width, depth, early_thr, mid_thr, draws, n_draws, seed, step_index, game_id,
+                     action_out, prob_out, n_consumed, n_expanded, trace_scores, trace_counts, trace_levels, 0);
+}
+
+static int beam_impl(const int32_t root[16], int valid_mask4, int width, int depth, int32_t early_thr, int32_t mid_thr,
+                     const uint32_t *draws, size_t n_draws, uint64_t seed, uint64_t step_index, uint64_t game_id,
+                     int *action_out, float *prob_out, uint32_t *n_consumed, uint32_t *n_expanded,
+                     double *trace_scores, int32_t *trace_counts, int trace_levels, int fixed_down)
+{
     if (width < 1 || width > G2048O_MAX_WIDTH) return -1;
     draw_src_t src; memset(&src, 0, sizeof src);
     src.explicit_draws = draws; src.n_explicit = n_draws; src.id = game_id;
@@ -421,7 +462,7 @@ int g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
     uint32_t expanded = 0;
     if (trace_counts) for (int l = 0; l < trace_levels; ++l) trace_counts[l] = 0;
 
-    int mask = valid_mask4 < 0 ? g2048o_agent_valid_mask(root) : (valid_mask4 & 15);   /* :82-84 */
+    int mask = valid_mask4 < 0 ? agent_valid_mask_opt(root, fixed_down) : (valid_mask4 & 15);   /* :82-84 */
     int nvalid = (mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1) + ((mask >> 3) & 1);
     if (n_consumed) *n_consumed = 0;
     if (n_expanded) *n_expanded = 0;
@@ -442,7 +483,7 @@ int g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
     for (int a = 0; a < 4; ++a) {                                                        /* :112-123 */
         if (!(mask & (1 << a))) continue;
         int32_t nbrd[16]; int v;
-        g2048o_agent_move(root, a, nbrd, NULL, &v);
+        agent_move_opt(root, a, nbrd, NULL, &v, fixed_down);
         if (!v) continue;
         if (count_zero16(nbrd) > 0) g2048o_spawn(nbrd, next_draw(&src));
         ++expanded;
@@ -471,11 +512,11 @@ int g2048o_beam_get_action(const int32_t root[16], int valid_mask4,
         int use_fast_eval = d > 3;
         int nn = 0;
         for (int c = 0; c < nb; ++c) {
-            int cmask = g2048o_agent_valid_mask(beam[c].board);
+            int cmask = agent_valid_mask_opt(beam[c].board, fixed_down);
             for (int a = 0; a < 4; ++a) {
                 if (!(cmask & (1 << a))) continue;
                 int32_t nbrd[16]; int v;
-                g2048o_agent_move(beam[c].board, a, nbrd, NULL, &v);
+                agent_move_opt(beam[c].board, a, nbrd, NULL, &v, fixed_down);
                 if (!v) continue;
                 if (count_zero16(nbrd) > 0) g2048o_spawn(nbrd, next_draw(&src));
                 ++expanded;
@@ -723,6 +764,23 @@ void g2048o_obs_batch(const uint8_t *boards, float *obs, size_t n)
         int32_t b[16];
         g2048o_unpack(boards + i * 16, b, 1);
         g2048o_normalize_state(b, obs + i * 16);
+    }
+}
+
+void g2048o_beam_batch_opt(const uint8_t *roots, const uint8_t *mask_or_null, uint8_t *action_out,
+                           float *prob_out, uint32_t *expanded_out, int width, int depth,
+                           int32_t early_thr, int32_t mid_thr,
+                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n, int fixed_down)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (size_t i = 0; i < n; ++i) {
+        int32_t b[16]; int a = 0; float p = 0.0f; uint32_t ne = 0;
+        g2048o_unpack(roots + i * 16, b, 1);
+        beam_impl(b, mask_or_null ? (int)(mask_or_null[i] & 15) : -1, width, depth, early_thr, mid_thr, NULL, 0, seed,
+                  step_index, game_id_base + i, &a, &p, NULL, &ne, NULL, NULL, 0, fixed_down);
+        action_out[i] = (uint8_t)a;
+        prob_out[i] = p;
+        if (expanded_out) expanded_out[i] = ne;
     }
 }
 

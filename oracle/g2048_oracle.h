@@ -97,6 +97,11 @@ void g2048o_beam_batch(const uint8_t *roots, const uint8_t *mask_or_null, uint8_
                        float *prob_out, uint32_t *expanded_out, int width, int depth,
                        int32_t early_thr, int32_t mid_thr,
                        uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n);
+/* fixed_down != 0: the product's non-parity option (true DOWN instead of the reference's rot180 quirk) */
+void g2048o_beam_batch_opt(const uint8_t *roots, const uint8_t *mask_or_null, uint8_t *action_out,
+                           float *prob_out, uint32_t *expanded_out, int width, int depth,
+                           int32_t early_thr, int32_t mid_thr,
+                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n, int fixed_down);
 int  g2048o_sample_action(const float p[4], int mask4, uint32_t h, float *prob);     /* ppo_agent.py:211-221 */
 void g2048o_sample_batch(const float *probs, const uint8_t *mask_or_null, uint8_t *actions, float *prob,
                          uint64_t seed, uint64_t step_index, uint64_t id_base, size_t n);

@@ -76,6 +76,8 @@ def lib():
             "g2048o_obs_batch": (None, [u8p, f32p, C.c_size_t]),
             "g2048o_beam_batch": (None, [u8p, u8p, u8p, f32p, u32p, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                          C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
+            "g2048o_beam_batch_opt": (None, [u8p, u8p, u8p, f32p, u32p, C.c_int, C.c_int, C.c_int32, C.c_int32,
+                                             C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]),
             "g2048o_sample_action": (C.c_int, [f32p, C.c_int, C.c_uint32, f32p]),
             "g2048o_sample_batch": (None, [f32p, u8p, u8p, f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
             "g2048o_num_threads": (C.c_int, []),
@@ -282,16 +284,16 @@ def obs_batch(boards):
 
 
 def beam_batch(roots, width, depth, mask=None, early_thr=512, mid_thr=1024, seed=0x2048, step_index=0,
-               game_id_base=0):
+               game_id_base=0, fixed_down=False):
     bi = np.ascontiguousarray(roots, dtype=np.uint8).reshape(-1, 16)
     n = bi.shape[0]
     mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     act = np.empty(n, dtype=np.uint8)
     prob = np.empty(n, dtype=np.float32)
     exp = np.empty(n, dtype=np.uint32)
-    lib().g2048o_beam_batch(_p(bi, C.c_uint8), _p(mk, C.c_uint8), _p(act, C.c_uint8), _p(prob, C.c_float),
-                            _p(exp, C.c_uint32), width, depth, early_thr, mid_thr, seed, step_index,
-                            game_id_base, n)
+    lib().g2048o_beam_batch_opt(_p(bi, C.c_uint8), _p(mk, C.c_uint8), _p(act, C.c_uint8), _p(prob, C.c_float),
+                                _p(exp, C.c_uint32), width, depth, early_thr, mid_thr, seed, step_index,
+                                game_id_base, n, int(fixed_down))
     return act, prob, exp
 
 

@@ -110,3 +110,16 @@ def test_beam_arbitrary_masks_and_random_fallback(ops):
         if int(a.item()) != g["action"][i] or float(p.item()) != g["prob"][i]:
             bad.append(i)
     assert not bad, bad
+
+
+def test_beam_fixed_down_option(ops, oracle):
+    """G2048_BEAM_FIXED_DOWN (true DOWN instead of the reference's rot180 quirk; NOT reference parity): checked against
+    the oracle's equally modified restatement, and shown to differ from the default on some roots."""
+    n = 1024
+    hb = oracle.synth_boards(n, seed=81, p_empty=0.3, max_code=10)
+    a, p, e = ops.beam_get_action(dev(hb), 10, 12, seed=3, step_index=2, fixed_down=True, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(hb, 10, 12, seed=3, step_index=2, fixed_down=True)
+    assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+    a0, _ = ops.beam_get_action(dev(hb), 10, 12, seed=3, step_index=2)
+    assert (a0.cpu().numpy() != oa).any()
