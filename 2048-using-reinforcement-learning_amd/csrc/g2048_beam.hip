@@ -39,8 +39,9 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                                                  uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
                                                  uint32_t *__restrict__ expanded_out, int width, int depth,
                                                  uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
-                                                 uint64_t id_base, bool fixed_down)
+                                                 uint64_t id_base, bool fixed_down, const uint32_t *__restrict__ keyblock)
 {
+    if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
     __shared__ uint4 s_board[kMaxWidth];                        // the beam, rank order
     __shared__ uint32_t s_root[kMaxWidth];                      // root action | (max code << 8) of each beam entry
     __shared__ uint4 s_cboard[64 * PASSES];                     // moved (pre-spawn) boards of the VALID children,
@@ -229,10 +230,10 @@ extern "C" {
 const char *g2048_last_error(void);
 void g2048_set_last_error_(const char *msg);
 
-int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
-                          float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
-                          int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
-                          uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                     float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                     int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, const uint32_t *keyblock)
 {
     if (n_games == 0) return G2048_OK;
     if (!root_boards || !action_out || !prob_out) { g2048_set_last_error_("g2048_beam_get_action: null pointer"); return G2048_ERR_ARG; }
@@ -249,14 +250,33 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
     if (4 * width <= 64)
         hipLaunchKernelGGL(beam_kernel<1>, grid, block, 0, s, roots, valid_mask_or_null, action_out, prob_out,
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold,
-                           k.k0, k.k1, game_id_base, fd);
+                           k.k0, k.k1, game_id_base, fd, keyblock);
     else
         hipLaunchKernelGGL(beam_kernel<2>, grid, block, 0, s, roots, valid_mask_or_null, action_out, prob_out,
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold,
-                           k.k0, k.k1, game_id_base, fd);
+                           k.k0, k.k1, game_id_base, fd, keyblock);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;
+}
+
+int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                          float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                          int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                          uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+{
+    return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
+                     mid_threshold, seed, step_index, game_id_base, n_games, opts, stream, nullptr);
+}
+
+int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                              float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                              int early_threshold, int mid_threshold, const uint32_t *keyblock,
+                              uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+{
+    if (!keyblock) { g2048_set_last_error_("g2048_beam_get_action_dyn: null key block"); return G2048_ERR_ARG; }
+    return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
+                     mid_threshold, 0, 0, game_id_base, n_games, opts, stream, keyblock);
 }
 
 }  // extern "C"

@@ -38,6 +38,9 @@ int check_launch(const char *what)
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
+// device key block (uint32[G2048_KEYBLOCK_WORDS]) read by the *_dyn entry points
+enum { KB_STEP = 0, KB_EPISODE = 2, KB_BEAM = 4, KB_POLICY = 6, KB_INDEX = 8 };
+
 constexpr int kBlock = 256;
 constexpr int kStepBoardsPerLane = 1;     // default of g2048_step: measured fastest (profiles/r01_step_tune.txt)
 inline unsigned blocks_for(size_t n, int per_block = kBlock) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -67,8 +70,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                                                      void *__restrict__ reward_out,
                                                      uint8_t *__restrict__ flags_out,
                                                      uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
-                                                     uint64_t id_base, size_t n)
+                                                     uint64_t id_base, size_t n, const uint32_t *__restrict__ keyblock)
 {
+    if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
     const size_t block0 = (size_t)blockIdx.x * (BLOCK * B);
     const uint4 *bin = boards_in + block0;
@@ -141,8 +145,9 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const uint8_t *__restrict
                                                       uint8_t *__restrict__ alive, int32_t *__restrict__ moves,
                                                       int32_t *__restrict__ valid_cnt, int32_t *__restrict__ invalid_cnt,
                                                       int4 *__restrict__ milestone, unsigned long long *__restrict__ expanded_sum,
-                                                      int32_t move_index, size_t n)
+                                                      int32_t move_index, size_t n, const uint32_t *__restrict__ keyblock)
 {
+    if (keyblock) move_index = (int32_t)keyblock[KB_INDEX];
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     if (!alive[i]) return;
@@ -167,8 +172,10 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const uint8_t *__restrict
 // ----------------------------------------------------------------- policy -----
 __global__ __launch_bounds__(kBlock) void sample_kernel(const float4 *__restrict__ probs, const uint8_t *__restrict__ mask,
                                                        uint8_t *__restrict__ actions, float *__restrict__ prob_out,
-                                                       uint32_t k0, uint32_t k1, uint64_t id_base, size_t n)
+                                                       uint32_t k0, uint32_t k1, uint64_t id_base, size_t n,
+                                                       const uint32_t *__restrict__ keyblock)
 {
+    if (keyblock) { k0 = keyblock[KB_POLICY]; k1 = keyblock[KB_POLICY + 1]; }
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 p = probs[i];
@@ -303,6 +310,20 @@ __global__ __launch_bounds__(kBlock) void metrics_kernel(const uint4 *__restrict
     if (threadIdx.x < 22 && acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
 }
 
+// ------------------------------------------------------------ key block -------
+// One thread: keys of every per-move domain at index *counter, then *counter += 1. Put in front of the *_dyn
+// kernels of one move, it makes that move's kernel sequence replayable from a captured hipGraph.
+__global__ void keys_advance_kernel(uint32_t *keyblock, unsigned long long *counter, uint64_t seed)
+{
+    const uint64_t idx = *counter;
+    const Keys s = rng_keys(seed, DOM_STEP, idx), e = rng_keys(seed, DOM_EPISODE, idx);
+    const Keys b = rng_keys(seed, DOM_BEAM, idx), p = rng_keys(seed, DOM_POLICY, idx);
+    keyblock[KB_STEP] = s.k0; keyblock[KB_STEP + 1] = s.k1; keyblock[KB_EPISODE] = e.k0; keyblock[KB_EPISODE + 1] = e.k1;
+    keyblock[KB_BEAM] = b.k0; keyblock[KB_BEAM + 1] = b.k1; keyblock[KB_POLICY] = p.k0; keyblock[KB_POLICY + 1] = p.k1;
+    keyblock[KB_INDEX] = (uint32_t)idx; keyblock[KB_INDEX + 1] = (uint32_t)(idx >> 32);
+    *counter = idx + 1ull;
+}
+
 // -------------------------------------------------------------- self-test -----
 __global__ void selftest_kernel(uint32_t *result, uint32_t a, uint32_t b, double x, double y, double z)
 {
@@ -340,9 +361,9 @@ int g2048_device_count(void)
     return n;
 }
 
-int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
-               void *reward_out, uint8_t *flags_out, uint64_t seed, uint64_t step_index,
-               uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
+static int step_impl(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+                     void *reward_out, uint8_t *flags_out, uint64_t seed, uint64_t step_index,
+                     uint64_t board_id_base, size_t n, uint32_t opts, void *stream, const uint32_t *keyblock)
 {
     if (n == 0) return G2048_OK;
     if (!boards_in || !actions || !boards_out || !score_inout || !reward_out || !flags_out)
@@ -360,7 +381,7 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, 
     const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : kStepBoardsPerLane;
 #define G2048_LAUNCH_STEP(F, A, BB) \
     hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, in, actions, out, \
-                       score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n)
+                       score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
 #define G2048_LAUNCH_STEP_B(F, A) \
     do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
          else G2048_LAUNCH_STEP(F, A, 4); } while (0)
@@ -371,6 +392,23 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, 
 #undef G2048_LAUNCH_STEP_B
 #undef G2048_LAUNCH_STEP
     return check_launch("g2048_step");
+}
+
+int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+               void *reward_out, uint8_t *flags_out, uint64_t seed, uint64_t step_index,
+               uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
+{
+    return step_impl(boards_in, actions, boards_out, score_inout, reward_out, flags_out, seed, step_index, board_id_base, n,
+                     opts, stream, nullptr);
+}
+
+int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+                   void *reward_out, uint8_t *flags_out, const uint32_t *keyblock, uint64_t board_id_base, size_t n,
+                   uint32_t opts, void *stream)
+{
+    if (!keyblock) return fail(G2048_ERR_ARG, "g2048_step_dyn: null key block");
+    return step_impl(boards_in, actions, boards_out, score_inout, reward_out, flags_out, 0, 0, board_id_base, n, opts, stream,
+                     keyblock);
 }
 
 int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch, uint64_t board_id_base,
@@ -398,9 +436,10 @@ int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t
     return check_launch("g2048_valid_moves");
 }
 
-int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
-                         int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
-                         unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream)
+static int track_impl(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+                      int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
+                      unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream,
+                      const uint32_t *keyblock)
 {
     if (n == 0) return G2048_OK;
     if (!flags || !alive_inout || !moves_inout || !valid_inout || !invalid_inout || !milestone_move_inout)
@@ -408,20 +447,51 @@ int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null,
     if (!aligned16(milestone_move_inout)) return fail(G2048_ERR_ARG, "g2048_track_episodes: milestone array must be 16-byte aligned");
     hipLaunchKernelGGL(track_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), flags,
                        expanded_or_null, alive_inout, moves_inout, valid_inout, invalid_inout,
-                       reinterpret_cast<int4 *>(milestone_move_inout), expanded_sum_inout_or_null, move_index, n);
+                       reinterpret_cast<int4 *>(milestone_move_inout), expanded_sum_inout_or_null, move_index, n, keyblock);
     return check_launch("g2048_track_episodes");
 }
 
-int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
-                         uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream)
+int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+                         int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
+                         unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream)
+{
+    return track_impl(flags, expanded_or_null, alive_inout, moves_inout, valid_inout, invalid_inout, milestone_move_inout,
+                      expanded_sum_inout_or_null, move_index, n, stream, nullptr);
+}
+
+int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+                             int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
+                             unsigned long long *expanded_sum_inout_or_null, const uint32_t *keyblock, size_t n, void *stream)
+{
+    if (!keyblock) return fail(G2048_ERR_ARG, "g2048_track_episodes_dyn: null key block");
+    return track_impl(flags, expanded_or_null, alive_inout, moves_inout, valid_inout, invalid_inout, milestone_move_inout,
+                      expanded_sum_inout_or_null, 0, n, stream, keyblock);
+}
+
+static int sample_impl(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                       uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream, const uint32_t *keyblock)
 {
     if (n == 0) return G2048_OK;
     if (!probs || !actions_out || !prob_out) return fail(G2048_ERR_ARG, "g2048_sample_actions: null pointer");
     if (!aligned16(probs) || !aligned4(prob_out)) return fail(G2048_ERR_ARG, "g2048_sample_actions: misaligned array");
     const Keys k = rng_keys(seed, DOM_POLICY, step_index);
     hipLaunchKernelGGL(sample_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4 *>(probs), mask4_or_null, actions_out, prob_out, k.k0, k.k1, env_id_base, n);
+                       reinterpret_cast<const float4 *>(probs), mask4_or_null, actions_out, prob_out, k.k0, k.k1, env_id_base, n,
+                       keyblock);
     return check_launch("g2048_sample_actions");
+}
+
+int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                         uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream)
+{
+    return sample_impl(probs, mask4_or_null, actions_out, prob_out, seed, step_index, env_id_base, n, stream, nullptr);
+}
+
+int g2048_sample_actions_dyn(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                             const uint32_t *keyblock, uint64_t env_id_base, size_t n, void *stream)
+{
+    if (!keyblock) return fail(G2048_ERR_ARG, "g2048_sample_actions_dyn: null key block");
+    return sample_impl(probs, mask4_or_null, actions_out, prob_out, 0, 0, env_id_base, n, stream, keyblock);
 }
 
 int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null, void *succ_boards_out,
@@ -526,6 +596,15 @@ int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flag
     hipLaunchKernelGGL(metrics_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint4 *>(boards), score, flags_or_null, expanded_or_null, out24, n);
     return check_launch("g2048_metrics");
+}
+
+int g2048_keys_advance(uint32_t *keyblock_out, unsigned long long *counter_inout, uint64_t seed, void *stream)
+{
+    if (!keyblock_out || !counter_inout) return fail(G2048_ERR_ARG, "g2048_keys_advance: null pointer");
+    if ((reinterpret_cast<uintptr_t>(counter_inout) & 7u) || !aligned4(keyblock_out))
+        return fail(G2048_ERR_ARG, "g2048_keys_advance: misaligned pointer");
+    hipLaunchKernelGGL(keys_advance_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), keyblock_out, counter_inout, seed);
+    return check_launch("g2048_keys_advance");
 }
 
 int g2048_selftest(uint32_t *result_out, void *stream)

@@ -20,6 +20,7 @@ VALID_ENV, VALID_AGENT = 0, 1
 EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING = range(8)
 BEAM_FIXED_DOWN = 0x01
 BEAM_MAX_WIDTH = 32
+KEYBLOCK_WORDS = 16
 
 _vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {
@@ -40,6 +41,11 @@ SIGNATURES = {
     "g2048_synth_boards": (_int, [_vp, _u64, _u64, _sz, _u32, _u32, _vp]),
     "g2048_synth_actions": (_int, [_vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_metrics": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2048_keys_advance": (_int, [_vp, _vp, _u64, _vp]),
+    "g2048_step_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _sz, _u32, _vp]),
+    "g2048_beam_get_action_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _u64, _sz, _u32, _vp]),
+    "g2048_sample_actions_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _sz, _vp]),
+    "g2048_track_episodes_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "g2048_selftest": (_int, [_vp, _vp]),
 }
 

@@ -28,7 +28,7 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_se
 
 def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
                          device="cuda", game_id_base=0, check_every=64, early_game_threshold=512,
-                         mid_game_threshold=1024, fixed_down=False):
+                         mid_game_threshold=1024, fixed_down=False, use_graph=True):
     dev = torch.device(device)
     n = int(num_games)
     t_start = time.perf_counter()
@@ -40,13 +40,48 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
     ms_move = torch.full((n, len(MILESTONES)), -1, dtype=torch.int32, device=dev)
     expanded_sum = torch.zeros(n, dtype=torch.int64, device=dev)
     t = 0
+    graph = None
+    if use_graph:
+        # One move = [keys_advance, beam, step (in place), track], all reading their RNG keys / move index from a device
+        # key block, captured once into a hipGraph and replayed per move: no per-move host work besides the replay.
+        kb = ops.KeyBlock(seed, 0, dev)
+        out = (torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+               torch.empty(n, dtype=torch.int32, device=dev))
+
+        def one_move():
+            kb.advance()
+            ops.beam_get_action(env.boards, beam_width, search_depth, None, early_game_threshold, mid_game_threshold,
+                                game_id_base=game_id_base, fixed_down=fixed_down, keyblock=kb, out=out)
+            ops.step(env.boards, out[0], env.scores, 0, 0, game_id_base, out=env.boards, reward=env.reward, flags=env.flags,
+                     keyblock=kb)
+            ops.track_episodes(env.flags, alive, moves, valid_cnt, invalid_cnt, ms_move, 0, out[2], expanded_sum, keyblock=kb)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            state = [x.clone() for x in (env.boards, env.scores, alive, moves, valid_cnt, invalid_cnt, ms_move, expanded_sum,
+                                         kb.counter)]
+            with torch.cuda.stream(side):
+                one_move()                      # warm-up outside capture (it also advances the state: restored below)
+                side.synchronize()
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    one_move()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for dst, src in zip((env.boards, env.scores, alive, moves, valid_cnt, invalid_cnt, ms_move, expanded_sum,
+                                 kb.counter), state):
+                dst.copy_(src)                  # capture does not execute, the warm-up did: rewind to move 0
+        except Exception:                       # noqa: BLE001 -- capture unavailable: plain launches
+            graph = None
     while t < max_moves:
-        actions, _, expanded = ops.beam_get_action(env.boards, beam_width, search_depth, None, early_game_threshold,
-                                                   mid_game_threshold, seed, t, game_id_base, fixed_down,
-                                                   want_expanded=True)
-        env.step(actions)
-        # evaluate_beam_search.py:42-64 for every game, one kernel
-        ops.track_episodes(env.flags, alive, moves, valid_cnt, invalid_cnt, ms_move, t, expanded, expanded_sum)
+        if graph is not None:
+            graph.replay()
+        else:
+            actions, _, expanded = ops.beam_get_action(env.boards, beam_width, search_depth, None, early_game_threshold,
+                                                       mid_game_threshold, seed, t, game_id_base, fixed_down,
+                                                       want_expanded=True)
+            env.step(actions)
+            # evaluate_beam_search.py:42-64 for every game, one kernel
+            ops.track_episodes(env.flags, alive, moves, valid_cnt, invalid_cnt, ms_move, t, expanded, expanded_sum)
         t += 1
         if t % check_every == 0 and not bool(alive.any()):
             break

@@ -12,13 +12,30 @@ def _dev(t):
     return t.device
 
 
+class KeyBlock:
+    """Device-resident per-move RNG keys (include/g2048.h, "graph-replayable loops"). `advance()` enqueues the
+    one-thread kernel that derives the keys of move `counter` and increments the counter; the ops below accept
+    `keyblock=` instead of a host step index, which makes a captured hipGraph of one move replayable."""
+
+    def __init__(self, seed, start=0, device="cuda"):
+        self.seed = int(seed)
+        self.device = torch.device(device)
+        self.words = torch.zeros(L.KEYBLOCK_WORDS, dtype=torch.int32, device=self.device)
+        self.counter = torch.full((1,), int(start), dtype=torch.int64, device=self.device)
+
+    def advance(self):
+        L.call(self.device, L.lib().g2048_keys_advance, self.words.data_ptr(), self.counter.data_ptr(), L.u64(self.seed),
+               L.stream_ptr(self.device))
+        return self
+
+
 def _require_scores(scores):
     """scores are 32-bit on the device (the ABI's uint32); torch code usually holds them as int32."""
     L.require_device_tensor(scores, torch.uint32 if scores.dtype == torch.uint32 else torch.int32, None, "scores")
 
 
 def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=None, flags=None,
-         reward_f64=False, auto_reset=False, tune=0):
+         reward_f64=False, auto_reset=False, tune=0, keyblock=None):
     """Game2048Env.step for every board (reference environment/game_2048.py:170-210).
 
     scores (uint32) is updated in place. Returns (boards_out, reward, flags); flags bit0 = done,
@@ -41,9 +58,13 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) | ((int(tune) & 3) << 8)
-    L.call(dev, L.lib().g2048_step, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
-                               reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base),
-                               n, opts, L.stream_ptr(dev))
+    if keyblock is not None:        # keys (and so seed / step index) come from the device key block
+        L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+               reward.data_ptr(), flags.data_ptr(), keyblock.words.data_ptr(), L.u64(id_base), n, opts, L.stream_ptr(dev))
+    else:
+        L.call(dev, L.lib().g2048_step, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+               reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), n, opts,
+               L.stream_ptr(dev))
     return out, reward, flags
 
 
@@ -100,7 +121,7 @@ def obs(boards, out=None):
 
 
 def track_episodes(flags, alive, moves, valid_cnt, invalid_cnt, milestone_move, move_index, expanded=None,
-                   expanded_sum=None):
+                   expanded_sum=None, keyblock=None):
     """One-kernel bookkeeping of the evaluation loop (reference evaluate_beam_search.py:42-64); all tensors are
     updated in place. alive uint8 (n,), moves/valid_cnt/invalid_cnt int32 (n,), milestone_move int32 (n,8)."""
     n = flags.shape[0]
@@ -112,14 +133,16 @@ def track_episodes(flags, alive, moves, valid_cnt, invalid_cnt, milestone_move, 
     if expanded is not None:
         L.require_device_tensor(expanded, torch.int32, None, "expanded")
         L.require_device_tensor(expanded_sum, torch.int64, None, "expanded_sum")
-    L.call(flags.device, L.lib().g2048_track_episodes, flags.data_ptr(), expanded.data_ptr() if expanded is not None else None,
-                                         alive.data_ptr(), moves.data_ptr(), valid_cnt.data_ptr(), invalid_cnt.data_ptr(),
-                                         milestone_move.data_ptr(),
-                                         expanded_sum.data_ptr() if expanded is not None else None,
-                                         int(move_index), n, L.stream_ptr(flags.device))
+    args = (flags.data_ptr(), expanded.data_ptr() if expanded is not None else None, alive.data_ptr(), moves.data_ptr(),
+            valid_cnt.data_ptr(), invalid_cnt.data_ptr(), milestone_move.data_ptr(),
+            expanded_sum.data_ptr() if expanded is not None else None)
+    if keyblock is not None:
+        L.call(flags.device, L.lib().g2048_track_episodes_dyn, *args, keyblock.words.data_ptr(), n, L.stream_ptr(flags.device))
+    else:
+        L.call(flags.device, L.lib().g2048_track_episodes, *args, int(move_index), n, L.stream_ptr(flags.device))
 
 
-def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, actions=None, prob=None):
+def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, actions=None, prob=None, keyblock=None):
     """Masked categorical sampling (PPOAgent.get_action, agents/ppo_agent.py:211-221) for every env in one kernel.
     probs float32 (n,4); mask4 uint8 (n,) or None. Returns (actions uint8 (n,), prob float32 (n,))."""
     L.require_device_tensor(probs, torch.float32, (4,), "probs")
@@ -133,9 +156,13 @@ def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, acti
         prob = torch.empty(n, dtype=torch.float32, device=dev)
     L.require_device_tensor(actions, torch.uint8, None, "actions")
     L.require_device_tensor(prob, torch.float32, None, "prob")
-    L.call(dev, L.lib().g2048_sample_actions, probs.data_ptr(), mask4.data_ptr() if mask4 is not None else None,
-                                         actions.data_ptr(), prob.data_ptr(), L.u64(seed), L.u64(step_index),
-                                         L.u64(id_base), n, L.stream_ptr(dev))
+    mp = mask4.data_ptr() if mask4 is not None else None
+    if keyblock is not None:
+        L.call(dev, L.lib().g2048_sample_actions_dyn, probs.data_ptr(), mp, actions.data_ptr(), prob.data_ptr(),
+               keyblock.words.data_ptr(), L.u64(id_base), n, L.stream_ptr(dev))
+    else:
+        L.call(dev, L.lib().g2048_sample_actions, probs.data_ptr(), mp, actions.data_ptr(), prob.data_ptr(), L.u64(seed),
+               L.u64(step_index), L.u64(id_base), n, L.stream_ptr(dev))
     return actions, prob
 
 
@@ -211,7 +238,8 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
 
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
-                    seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False):
+                    seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
+                    out=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
     Returns (actions uint8, probs float32[, expanded int32])."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
@@ -223,16 +251,21 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
         if valid_mask.shape[0] != n:
             raise ValueError("g2048: valid_mask length must equal the number of roots")
     dev = roots.device
-    actions = torch.empty(n, dtype=torch.uint8, device=dev)
-    probs = torch.empty(n, dtype=torch.float32, device=dev)
-    expanded = torch.empty(n, dtype=torch.int32, device=dev) if want_expanded else None
-    L.call(dev, L.lib().g2048_beam_get_action, roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None,
-                                          actions.data_ptr(), probs.data_ptr(),
-                                          expanded.data_ptr() if expanded is not None else None,
-                                          int(width), int(depth), int(early_threshold), int(mid_threshold),
-                                          L.u64(seed), L.u64(step_index), L.u64(game_id_base), n,
-                                          L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev))
-    return (actions, probs, expanded) if want_expanded else (actions, probs)
+    if out is not None:             # (actions, probs, expanded) buffers to reuse, e.g. inside a captured graph
+        actions, probs, expanded = out
+    else:
+        actions = torch.empty(n, dtype=torch.uint8, device=dev)
+        probs = torch.empty(n, dtype=torch.float32, device=dev)
+        expanded = torch.empty(n, dtype=torch.int32, device=dev) if want_expanded else None
+    head = (roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None, actions.data_ptr(), probs.data_ptr(),
+            expanded.data_ptr() if expanded is not None else None, int(width), int(depth), int(early_threshold),
+            int(mid_threshold))
+    tail = (L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev))
+    if keyblock is not None:
+        L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
+    else:
+        L.call(dev, L.lib().g2048_beam_get_action, *head, L.u64(seed), L.u64(step_index), *tail)
+    return (actions, probs, expanded) if (want_expanded or (out is not None and expanded is not None)) else (actions, probs)
 
 
 def selftest(device="cuda"):

@@ -158,6 +158,29 @@ int g2048_synth_actions(uint8_t *actions_out, uint64_t seed, uint64_t step_index
 int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flags_or_null,
                   const uint32_t *expanded_or_null, unsigned long long *out24, size_t n, void *stream);
 
+/* ---- graph-replayable loops -------------------------------------------------------------------------------
+ * The entry points above take the step / decision index as a host scalar, so a captured hipGraph bakes it in. For
+ * loops that replay ONE captured move many times (evaluation driver, rollouts), the per-move keys can live in a
+ * device key block instead: g2048_keys_advance (one thread) writes the keys of every per-move RNG domain for index
+ * *counter into keyblock_out[G2048_KEYBLOCK_WORDS] and increments *counter; the *_dyn variants read their keys (and
+ * g2048_track_episodes_dyn its move index) from that block. Results are identical to the scalar forms called with
+ * step_index = the counter's value. */
+#define G2048_KEYBLOCK_WORDS 16
+int g2048_keys_advance(uint32_t *keyblock_out, unsigned long long *counter_inout, uint64_t seed, void *stream);
+int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+                   void *reward_out, uint8_t *flags_out, const uint32_t *keyblock, uint64_t board_id_base, size_t n,
+                   uint32_t opts, void *stream);
+int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                              float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                              int early_threshold, int mid_threshold, const uint32_t *keyblock,
+                              uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream);
+int g2048_sample_actions_dyn(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+                             const uint32_t *keyblock, uint64_t env_id_base, size_t n, void *stream);
+int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout,
+                             int32_t *moves_inout, int32_t *valid_inout, int32_t *invalid_inout,
+                             int32_t *milestone_move_inout, unsigned long long *expanded_sum_inout_or_null,
+                             const uint32_t *keyblock, size_t n, void *stream);
+
 /* device self-test of the instruction-level assumptions the kernels rely on (v_perm_b32 byte order,
  * udot4, f64 contraction off). Writes 0 to *result_out (device uint32) when all hold. */
 int g2048_selftest(uint32_t *result_out, void *stream);

@@ -75,3 +75,38 @@ def test_quality_matches_reference_report(g2048):
     assert 12000 < s["average_score"] < 26000
     assert 900 < s["average_highest_tile"] < 1800
     assert s["highest_tile"] >= 2048
+
+
+def test_dyn_entry_points_equal_scalar_forms(g2048):
+    """The *_dyn entry points (keys from the device key block) == the scalar forms at step_index = counter."""
+    from g2048 import ops
+    dev_ = "cuda:0"
+    n, seed = 30000, 0xABCDEF
+    b = ops.synth_boards(n, seed=3, device=dev_)
+    a = ops.synth_actions(n, seed=3, step_index=0, device=dev_)
+    kb = ops.KeyBlock(seed, start=41, device=dev_)
+    for t in (41, 42, 43):
+        kb.advance()
+        sc1 = torch.zeros(n, dtype=torch.int32, device=dev_); sc2 = torch.zeros_like(sc1)
+        o1, r1, f1 = ops.step(b, a, sc1, seed, t, id_base=7, reward_f64=True, auto_reset=True)
+        o2, r2, f2 = ops.step(b, a, sc2, 0, 0, id_base=7, reward_f64=True, auto_reset=True, keyblock=kb)
+        assert bool((o1 == o2).all()) and bool((f1 == f2).all()) and bool((sc1 == sc2).all())
+        assert np.array_equal(r1.cpu().numpy(), r2.cpu().numpy(), equal_nan=True)
+        a1, p1, e1 = ops.beam_get_action(b[:512], 20, 30, seed=seed, step_index=t, game_id_base=5, want_expanded=True)
+        a2, p2, e2 = ops.beam_get_action(b[:512], 20, 30, game_id_base=5, want_expanded=True, keyblock=kb)
+        assert bool((a1 == a2).all()) and bool((p1 == p2).all()) and bool((e1 == e2).all())
+        probs = torch.softmax(torch.randn(n, 4, device=dev_), 1)
+        m = ops.valid_moves(b)
+        s1, q1 = ops.sample_actions(probs, m, seed=seed, step_index=t, id_base=9)
+        s2, q2 = ops.sample_actions(probs, m, id_base=9, keyblock=kb)
+        assert bool((s1 == s2).all()) and bool((q1 == q2).all())
+    assert int(kb.counter.item()) == 44 and int(kb.words[8].item()) == 43
+
+
+def test_graph_replayed_driver_equals_plain_driver(g2048):
+    kw = dict(num_games=96, beam_width=6, search_depth=8, seed=99, max_moves=500, check_every=16)
+    r0 = g2048.evaluate_beam_search(use_graph=False, **kw)
+    r1 = g2048.evaluate_beam_search(use_graph=True, **kw)
+    for k in ("scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games", "total_expansions"):
+        assert r0[k] == r1[k], k
+    assert np.array_equal(r0["final_boards"], r1["final_boards"])
