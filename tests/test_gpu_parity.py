@@ -323,3 +323,24 @@ def test_simulate_move_f4(ops, oracle):
         assert ns.dtype == np.int32 and np.array_equal(ns, s[k]) and rr == r[k] and dd == bool(d[k])
         assert isinstance(rr, np.float64) and isinstance(dd, bool)
     assert np.array_equal(env.board, before[0]) and env.score == before[1] and env.highest_tile == before[2]
+
+
+@pytest.mark.parametrize("p_empty,max_code", [(0.0, 2), (0.02, 4), (0.3, 17), (0.7, 17), (0.95, 3)])
+def test_step_fuzz_all_modes(ops, oracle, p_empty, max_code):
+    """Differential fuzz: 2 Mi boards per distribution (dense low tiles ... sparse huge tiles), every template mode of
+    the step kernel (f64 / f32 reward x auto-reset on / off), three consecutive steps each, against the oracle."""
+    n = 1 << 21
+    hb = oracle.synth_boards(n, seed=1000 + max_code, id_base=5 << 33, p_empty=p_empty, max_code=max_code)
+    for f64 in (True, False):
+        for ar in (False, True):
+            b = dev(hb); hcur = hb
+            sc = torch.zeros(n, dtype=torch.int32, device=DEV); hsc = np.zeros(n, np.uint32)
+            for t in range(3):
+                ha = oracle.synth_actions(n, seed=77, step_index=t, id_base=5 << 33)
+                out, rw, fl = ops.step(b, dev(ha), sc, seed=77, step_index=t, id_base=5 << 33, reward_f64=f64, auto_reset=ar)
+                hcur, hsc, hrw, hfl = oracle.step_batch(hcur, ha, hsc, seed=77, step_index=t, id_base=5 << 33, opts=int(ar))
+                assert np.array_equal(host(out), hcur) and np.array_equal(host(fl), hfl)
+                assert np.array_equal(host(sc).astype(np.uint32), hsc)
+                want = hrw if f64 else hrw.astype(np.float32)
+                assert np.array_equal(host(rw), want, equal_nan=True)
+                b = out
