@@ -123,3 +123,16 @@ def test_beam_fixed_down_option(ops, oracle):
     assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
     a0, _ = ops.beam_get_action(dev(hb), 10, 12, seed=3, step_index=2)
     assert (a0.cpu().numpy() != oa).any()
+
+
+@pytest.mark.parametrize("width,depth,p_empty,max_code", [(2, 35, 0.1, 5), (5, 9, 0.6, 12), (17, 26, 0.0, 3), (32, 30, 0.25, 17),
+                                                         (20, 30, 0.9, 2), (9, 3, 0.4, 9)])
+def test_beam_fuzz(ops, oracle, width, depth, p_empty, max_code):
+    """Differential fuzz over widths (one and two stage-B rounds), depths (incl. the depth clamps) and root
+    distributions (dead / full / nearly empty boards, huge tiles), game ids above 2^32."""
+    n = 2048
+    hb = oracle.synth_boards(n, seed=width * 100 + depth, p_empty=p_empty, max_code=max_code)
+    a, p, e = ops.beam_get_action(dev(hb), width, depth, seed=12, step_index=3, game_id_base=3 << 34, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(hb, width, depth, seed=12, step_index=3, game_id_base=3 << 34)
+    assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
