@@ -1,10 +1,23 @@
 /* abi_smoke.c -- drives include/g2048.h from plain C with nothing but the HIP runtime (no Python, no torch):
  * synthesises N boards and actions on the device, steps them T times in place, runs one beam decision for the
  * first G boards, and prints FNV-1a checksums of every output array. tests/test_gpu_abi_c.py compares the
- * checksums with the oracle's for the same seeds. Build: hipcc (as a C++ compiler) or gcc with -I/opt/rocm/include. */
-#define __HIP_PLATFORM_AMD__ 1
-#include <hip/hip_runtime_api.h>
+ * checksums with the oracle's for the same seeds. Build: gcc -std=c11 (tests/abi_c/Makefile). */
 #include <stdint.h>
+#include <stddef.h>
+
+/* the handful of HIP runtime entry points this client needs, declared by hand so that the file stays plain C with no
+ * HIP headers (libamdhip64's C API) */
+typedef int hipError_t;
+typedef void *hipStream_t;
+#define hipSuccess 0
+#define hipMemcpyDeviceToHost 2
+hipError_t hipMalloc(void **ptr, size_t size);
+hipError_t hipMemset(void *dst, int value, size_t size);
+hipError_t hipMemcpy(void *dst, const void *src, size_t size, int kind);
+hipError_t hipStreamCreate(hipStream_t *stream);
+hipError_t hipStreamSynchronize(hipStream_t stream);
+const char *hipGetErrorString(hipError_t e);
+
 #include <stdio.h>
 #include <stdlib.h>
 
