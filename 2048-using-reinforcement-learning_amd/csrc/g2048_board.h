@@ -14,17 +14,24 @@
 // diverge on the action.
 //
 // What each routine implements (reference file:line) is stated at the routine.
-// Functions are __host__ __device__ so tests/hostsim can unit-test this exact
-// arithmetic on a CPU against the oracle; the product library only ever calls
-// them from kernels.
+// Under hipcc everything here is device code. The header is also compilable by a
+// plain host compiler -- tests/hostsim does that to unit-test this exact arithmetic
+// on a CPU against the oracle -- in which case the includer supplies stand-ins for
+// the two gfx950 builtins through G2048_PERM / G2048_UDOT4; nothing in the product
+// does.
 #pragma once
 #include <stdint.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define G2048_HD __host__ __device__ __forceinline__
+#define G2048_HD __device__ __forceinline__
+#define G2048_PERM(s0, s1, sel) __builtin_amdgcn_perm((s0), (s1), (sel))
+#define G2048_UDOT4(a, b, c) __builtin_amdgcn_udot4((a), (b), (c), false)
 #else
 #define G2048_HD inline
+#if !defined(G2048_PERM) || !defined(G2048_UDOT4)
+#error "host builds of g2048_board.h (test harness only) must define G2048_PERM and G2048_UDOT4"
+#endif
 #endif
 
 namespace g2048 {
@@ -40,34 +47,12 @@ enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4
 // ---------------------------------------------------------------- intrinsics --
 // v_perm_b32: bytes of {s0:s1} (s1 = bytes 0..3, s0 = bytes 4..7) picked by the
 // selector bytes; selector 0x0c yields 0x00.
-G2048_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_perm(s0, s1, sel);
-#else
-    uint64_t v = ((uint64_t)s0 << 32) | s1;
-    uint32_t r = 0;
-    for (int k = 0; k < 4; ++k) {
-        uint32_t b = (sel >> (8 * k)) & 0xffu;
-        uint32_t byte = b < 8 ? (uint32_t)(v >> (8 * b)) & 0xffu : (b == 12 ? 0u : 0xffu);
-        r |= byte << (8 * k);
-    }
-    return r;
-#endif
-}
+G2048_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return G2048_PERM(s0, s1, sel); }
 
 G2048_HD uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }      // v_bcnt_u32_b32
 
 // sum over the 4 bytes of a[i]*b[i] + c  (v_dot4_u32_u8)
-G2048_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_udot4(a, b, c, false);
-#else
-    for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
-    return c;
-#endif
-}
+G2048_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return G2048_UDOT4(a, b, c); }
 
 // ------------------------------------------------------------------- flags ----
 // 0x80 in every byte lane that is non-zero / zero.

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "hostsim_intrinsics.h"      // portable stand-ins for v_perm_b32 / v_dot4_u32_u8, then the product header
 #include "g2048_board.h"
 #include "g2048_rng.h"
 

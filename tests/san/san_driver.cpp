@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 
+#include "../hostsim/hostsim_intrinsics.h"
 #include "g2048_board.h"
 #include "g2048_rng.h"
 extern "C" {
