@@ -1,7 +1,7 @@
 // hostsim.cpp -- TEST HARNESS ONLY (lives under tests/, never shipped, never loaded by the product).
 //
-// Compiles csrc/g2048_board.h -- the exact per-board arithmetic the HIP kernels run, with the three
-// gfx950 intrinsics (v_perm_b32, v_bcnt, v_dot4_u32_u8) emulated in portable C++ -- for the host CPU,
+// Compiles csrc/g2048_board.h -- the exact per-board arithmetic the HIP kernels run, with the two
+// gfx950 builtins (v_perm_b32, v_dot4_u32_u8) replaced by portable stand-ins (hostsim_intrinsics.h) -- for the host CPU,
 // so the `-m "not gpu"` suite can check every SWAR routine against the oracle without a GPU. It is not
 // a CPU back-end: include/g2048.h has no entry point that reaches this code.
 #include <stddef.h>
