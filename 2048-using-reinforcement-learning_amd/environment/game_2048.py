@@ -6,7 +6,9 @@ One board living on the GPU and stepped by the same HIP kernel that steps millio
 `g2048.VecGame2048`. Differences from the reference, all deliberate:
   * tile spawns come from the engine's counter RNG, not from Python's global `random`
     (the seed defaults to one draw from `random`, so `random.seed(k)` still pins a run);
-  * size != 4 raises (the reference's agents hard-code 4x4: beam_search_agent.py:69,378).
+  * size != 4 raises (the reference's agents hard-code 4x4: beam_search_agent.py:69,378);
+  * step(action) with an action outside 0..3 raises ValueError (the reference silently treats it as a move that
+    changes nothing; the batched kernels use the low two bits of the action byte).
 """
 import random
 
@@ -92,7 +94,9 @@ class Game2048Env:
         return [bool((m >> a) & 1) for a in range(4)]
 
     def step(self, action):                                    # reference :170-210
-        self._action.fill_(int(action) & 3)
+        if int(action) not in (0, 1, 2, 3):
+            raise ValueError("Game2048Env.step: action must be 0 (LEFT), 1 (UP), 2 (RIGHT) or 3 (DOWN)")
+        self._action.fill_(int(action))
         ops.step(self._boards, self._action, self._scores, self.seed, self._t, 0, out=self._boards,
                  reward=self._reward, flags=self._flags, reward_f64=True)
         self._t += 1
