@@ -62,7 +62,7 @@ __device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
 // board the kernel sits between the HBM and the VALU roofline, and a wave that only ever has one board
 // in flight serialises load latency -> compute -> store. A block owns 256*B consecutive boards; pass k
 // of a wave touches 64 consecutive boards (1 KiB per wave-instruction).
-template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK>
+template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
                                                      uint4 *boards_out,
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                                                      void *__restrict__ reward_out,
                                                      uint8_t *__restrict__ flags_out,
                                                      uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
-                                                     uint64_t id_base, size_t n, const uint32_t *__restrict__ keyblock)
+                                                     uint64_t id_base, size_t n, const uint32_t *__restrict__ keyblock,
+                                                     uint32_t a0 = 0, uint32_t a1 = 0)
 {
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
         if (full || j < lim) {
             prev[k] = load_board(bin, j);
-            action[k] = act[j];
+            if (!RANDOM_ACTIONS) action[k] = act[j];
             sc[k] = scp[j];
         }
     }
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
         if (!(full || j < lim)) break;
         const uint64_t id = id_base + block0 + j;
+        if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
         const StepOut o = step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id, 0u));
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
@@ -366,12 +368,14 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
                      uint64_t board_id_base, size_t n, uint32_t opts, void *stream, const uint32_t *keyblock)
 {
     if (n == 0) return G2048_OK;
-    if (!boards_in || !actions || !boards_out || !score_inout || !reward_out || !flags_out)
+    const bool random_actions = (opts & G2048_STEP_RANDOM_ACTIONS) != 0u;
+    if (!boards_in || (!actions && !random_actions) || !boards_out || !score_inout || !reward_out || !flags_out)
         return fail(G2048_ERR_ARG, "g2048_step: null pointer");
+    if (random_actions && keyblock) return fail(G2048_ERR_ARG, "g2048_step_dyn: RANDOM_ACTIONS needs the scalar form");
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
-    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | (3u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS | (3u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
     const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *in = static_cast<const uint4 *>(boards_in);
@@ -385,6 +389,18 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
 #define G2048_LAUNCH_STEP_B(F, A) \
     do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
          else G2048_LAUNCH_STEP(F, A, 4); } while (0)
+    if (random_actions) {           // uniform actions drawn in the kernel: (seed, SYNTH_ACTION, step_index, board id) >> 30
+        const Keys ak = rng_keys(seed, DOM_SYNTH_ACTION, step_index);
+#define G2048_LAUNCH_RANDOM(F, A) \
+        hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, in, actions, out, \
+                           score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock, ak.k0, ak.k1)
+        if (f64 && ar) G2048_LAUNCH_RANDOM(true, true);
+        else if (f64) G2048_LAUNCH_RANDOM(true, false);
+        else if (ar) G2048_LAUNCH_RANDOM(false, true);
+        else G2048_LAUNCH_RANDOM(false, false);
+#undef G2048_LAUNCH_RANDOM
+        return check_launch("g2048_step");
+    }
     if (f64 && ar) G2048_LAUNCH_STEP_B(true, true);
     else if (f64) G2048_LAUNCH_STEP_B(true, false);
     else if (ar) G2048_LAUNCH_STEP_B(false, true);

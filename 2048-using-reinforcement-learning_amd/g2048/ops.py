@@ -39,10 +39,17 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     """Game2048Env.step for every board (reference environment/game_2048.py:170-210).
 
     scores (uint32) is updated in place. Returns (boards_out, reward, flags); flags bit0 = done,
-    bit1 = valid move, bits 3..7 = max log2 code. `out` may be `boards` for an in-place step."""
+    bit1 = valid move, bits 3..7 = max log2 code. `out` may be `boards` for an in-place step.
+    actions=None: random playout, the kernel draws the uniform actions synth_actions(seed, step_index) would give."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     n = boards.shape[0]
-    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    random_actions = actions is None
+    if random_actions:
+        if keyblock is not None:
+            raise ValueError("g2048: random actions need the scalar (seed, step_index) form")
+        actions = boards        # placeholder for the length check below; the pointer passed is NULL
+    else:
+        L.require_device_tensor(actions, torch.uint8, None, "actions")
     _require_scores(scores)
     if actions.shape[0] != n or scores.shape[0] != n:
         raise ValueError("g2048: actions/scores length must equal the number of boards")
@@ -57,12 +64,14 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(out, torch.uint8, (16,), "out")
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
-    opts = (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) | ((int(tune) & 3) << 8)
+    opts = ((L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
+            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 3) << 8))
+    act_ptr = None if random_actions else actions.data_ptr()
     if keyblock is not None:        # keys (and so seed / step index) come from the device key block
-        L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+        L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),
                reward.data_ptr(), flags.data_ptr(), keyblock.words.data_ptr(), L.u64(id_base), n, opts, L.stream_ptr(dev))
     else:
-        L.call(dev, L.lib().g2048_step, boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(),
+        L.call(dev, L.lib().g2048_step, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),
                reward.data_ptr(), flags.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), n, opts,
                L.stream_ptr(dev))
     return out, reward, flags

@@ -76,8 +76,9 @@ class VecGame2048:
             self.scores.copy_(scores)
         return self.boards
 
-    def step(self, actions):
-        """actions uint8 (n,). Returns (boards, reward, done(bool), info) -- tensors, no host sync.
+    def step(self, actions=None):
+        """actions uint8 (n,), or None for a random playout step (uniform actions drawn inside the kernel, the same ones
+        `random_actions()` returns for this step). Returns (boards, reward, done(bool), info) -- tensors, no host sync.
         info: score, valid_move, highest_tile (as in game_2048.py:206-210)."""
         ops.step(self.boards, actions, self.scores, self.seed, self.t, self.id_base, out=self._spare,
                  reward=self.reward, flags=self.flags, reward_f64=self.reward_f64, auto_reset=self.auto_reset)

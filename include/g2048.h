@@ -49,6 +49,9 @@ enum {
 /* opts of g2048_step */
 #define G2048_STEP_REWARD_F64  0x01u   /* reward_out is double[n] (parity mode); default float[n] = (float)f64 reward */
 #define G2048_STEP_AUTO_RESET  0x02u   /* finished boards are replaced by a fresh episode (score 0); flags keep DONE */
+#define G2048_STEP_RANDOM_ACTIONS 0x04u /* random playouts: `actions` is ignored (may be NULL); board i moves in direction
+                                          draw(seed, SYNTH_ACTION, step_index, id) >> 30, exactly what g2048_synth_actions
+                                          writes for the same (seed, step_index, id) */
 
 /* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4 */
 #define G2048_STEP_TUNE_SHIFT  8

@@ -344,3 +344,17 @@ def test_step_fuzz_all_modes(ops, oracle, p_empty, max_code):
                 want = hrw if f64 else hrw.astype(np.float32)
                 assert np.array_equal(host(rw), want, equal_nan=True)
                 b = out
+
+
+def test_random_action_steps_equal_explicit_actions(ops):
+    """G2048_STEP_RANDOM_ACTIONS: the kernel's own uniform actions == synth_actions for the same (seed, step, id)."""
+    from g2048 import VecGame2048
+    n = 300001
+    e1 = VecGame2048(n, device=DEV, seed=5, id_base=1 << 35, auto_reset=True, reward_f64=True)
+    e2 = VecGame2048(n, device=DEV, seed=5, id_base=1 << 35, auto_reset=True, reward_f64=True)
+    for t in range(6):
+        a = e1.random_actions()
+        b1, r1, d1, _ = e1.step(a)
+        b2, r2, d2, _ = e2.step()
+        assert bool((b1 == b2).all()) and bool((d1 == d2).all()) and bool((e1.scores == e2.scores).all())
+        assert np.array_equal(host(r1), host(r2), equal_nan=True)
