@@ -34,37 +34,36 @@ __device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
+// LDS of one search (one wavefront = one game)
 template <int PASSES>
-__global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ roots, const uint8_t *__restrict__ mask_in,
-                                                 uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
-                                                 uint32_t *__restrict__ expanded_out, int width, int depth,
-                                                 uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
-                                                 uint64_t id_base, bool fixed_down, const uint32_t *__restrict__ keyblock)
-{
-    if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
-    __shared__ uint4 s_board[kMaxWidth];                        // the beam, rank order
-    __shared__ uint32_t s_root[kMaxWidth];                      // root action | (max code << 8) of each beam entry
-    __shared__ uint4 s_cboard[64 * PASSES];                     // moved (pre-spawn) boards of the VALID children,
-    __shared__ uint32_t s_croot[64 * PASSES];                   //   compacted in generation order, + root action | parent max << 8
-    __shared__ __align__(16) double s_score[64 * PASSES + 2];   // f64 scores (levels 1..3) or, reinterpreted, u32 keys
+struct BeamShared {
+    uint4 board[kMaxWidth];                         // the beam, rank order
+    uint32_t root[kMaxWidth];                       // root action | (max code << 8) of each beam entry
+    uint4 cboard[64 * PASSES];                      // moved (pre-spawn) boards of the VALID children,
+    uint32_t croot[64 * PASSES];                    //   compacted in generation order, + root action | parent max << 8
+    alignas(16) double score[64 * PASSES + 2];      // f64 scores (levels 1..3) or, reinterpreted, u32 keys
+};
 
+struct Decision { uint32_t action; float prob; uint32_t expanded; };
+
+// BeamSearchAgent.get_action for the game this wavefront owns. mask_in < 0: no caller mask. Every lane returns the
+// same Decision. Must be called by all 64 lanes (it contains workgroup barriers).
+template <int PASSES>
+__device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Board &root, int mask_in, int width, int depth,
+                                                uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1, uint64_t gid,
+                                                bool fixed_down)
+{
+    uint4 *const s_board = sh.board;
+    uint32_t *const s_root = sh.root;
+    uint4 *const s_cboard = sh.cboard;
+    uint32_t *const s_croot = sh.croot;
+    double *const s_score = sh.score;
     const uint32_t lane = threadIdx.x;
-    const size_t g = blockIdx.x;
-    const uint64_t gid = id_base + g;
-    const uint4 rv = roots[g];
-    const Board root = {{rv.x, rv.y, rv.z, rv.w}};
 
     // :82-93 -- caller mask or the agent's own validity; 0 or 1 valid move short-circuit
-    const uint32_t mask = mask_in ? (uint32_t)(mask_in[g] & 15u) : valid_mask_agent(root, fixed_down);
+    const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);
     const uint32_t nvalid = popc(mask);
-    if (nvalid <= 1u) {
-        if (lane == 0) {
-            action_out[g] = nvalid ? (uint8_t)__builtin_ctz(mask) : (uint8_t)0;
-            prob_out[g] = nvalid ? 1.0f : 0.5f;
-            if (expanded_out) expanded_out[g] = 0u;
-        }
-        return;
-    }
+    if (nvalid <= 1u) return Decision{nvalid ? (uint32_t)__builtin_ctz(mask) : 0u, nvalid ? 1.0f : 0.5f, 0u};
     // :96-106 -- phase and depth are fixed from the ROOT board
     const uint32_t root_max = max_code(root);
     const uint32_t phase = phase_of(root_max, early_thr, mid_thr);
@@ -121,15 +120,10 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
         expanded += total_valid;
         if (total_valid == 0u) {
             if (level == 0) {                                                   // :126-128 random valid action, prob 0.5
-                if (lane == 0) {
-                    uint32_t idx = ((rng_draw(k0, k1, gid, draws) >> 16) * nvalid) >> 16;
-                    uint32_t m = mask;
-                    while (idx--) m &= m - 1u;
-                    action_out[g] = (uint8_t)__builtin_ctz(m);
-                    prob_out[g] = 0.5f;
-                    if (expanded_out) expanded_out[g] = 0u;
-                }
-                return;
+                uint32_t idx = ((rng_draw(k0, k1, gid, draws) >> 16) * nvalid) >> 16;
+                uint32_t m = mask;
+                while (idx--) m &= m - 1u;
+                return Decision{(uint32_t)__builtin_ctz(m), 0.5f, 0u};
             }
             break;                                                              // :170-171 keep the previous beam
         }
@@ -215,10 +209,77 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
         nb = (int)min(total_valid, (uint32_t)width);
         __syncthreads();
     }
-    if (lane == 0) {                                                            // :178-181
-        action_out[g] = (uint8_t)(s_root[0] & 0xffu);
-        prob_out[g] = 1.0f;
+    const Decision d = {s_root[0] & 0xffu, 1.0f, expanded};                     // :178-181
+    __syncthreads();                                                            // s_root[0] read before any reuse of the LDS
+    return d;
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ roots, const uint8_t *__restrict__ mask_in,
+                                                 uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
+                                                 uint32_t *__restrict__ expanded_out, int width, int depth,
+                                                 uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
+                                                 uint64_t id_base, bool fixed_down, const uint32_t *__restrict__ keyblock)
+{
+    if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
+    __shared__ BeamShared<PASSES> sh;
+    const size_t g = blockIdx.x;
+    const uint4 rv = roots[g];
+    const Board root = {{rv.x, rv.y, rv.z, rv.w}};
+    const Decision d = beam_decide<PASSES>(sh, root, mask_in ? (int)(mask_in[g] & 15u) : -1, width, depth, early_thr, mid_thr,
+                                           k0, k1, id_base + g, fixed_down);
+    if (threadIdx.x == 0) {
+        action_out[g] = (uint8_t)d.action;
+        prob_out[g] = d.prob;
+        if (expanded_out) expanded_out[g] = d.expanded;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's evaluation loop (run_evaluation.py:48-69, evaluate_beam_search.py:16-98) fused per game: the
+// wavefront that owns a game alternates get_action (above) and Game2048Env.step until the game is over or the move cap
+// is reached, with the per-move bookkeeping (milestones, valid / invalid counters) in registers. No launch, no host,
+// no other game is involved between two moves; draws are the ones the step-by-step driver uses -- move t of game g
+// takes (seed, BEAM, t, g, j) for the search and (seed, STEP, t, g) for the spawn -- so the results are identical.
+template <int PASSES>
+__global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
+                                                 int32_t *__restrict__ moves_out, int32_t *__restrict__ valid_out,
+                                                 int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
+                                                 unsigned long long *__restrict__ expanded_out, uint8_t *__restrict__ alive_out,
+                                                 int width, int depth, uint32_t early_thr, uint32_t mid_thr, int max_moves,
+                                                 uint64_t seed, uint64_t id_base, bool fixed_down)
+{
+    __shared__ BeamShared<PASSES> sh;
+    const size_t g = blockIdx.x;
+    const uint64_t gid = id_base + g;
+    const uint4 rv = boards[g];
+    Board b = {{rv.x, rv.y, rv.z, rv.w}};
+    uint32_t sc = score[g];
+    int32_t ms[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int32_t nvalid = 0, ninvalid = 0, t = 0;
+    unsigned long long expanded = 0ull;
+    bool alive = true;
+    for (; t < max_moves && alive; ++t) {
+        const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)t), ks = rng_keys(seed, DOM_STEP, (uint64_t)t);
+        const Decision d = beam_decide<PASSES>(sh, b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
+        const StepOut o = step_board(b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u));
+        b = o.board;
+        sc += o.gain;
+        expanded += d.expanded;
+        const int32_t maxcode = (int32_t)(o.flags >> G2048_FLAG_MAXCODE_SHIFT);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (ms[k] < 0 && maxcode >= 6 + k) ms[k] = t;          // evaluate_beam_search.py:60-64
+        if (o.flags & G2048_FLAG_VALID) ++nvalid; else ++ninvalid;
+        alive = !(o.flags & G2048_FLAG_DONE);
+    }
+    if (threadIdx.x == 0) {
+        boards[g] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+        score[g] = sc;
+        moves_out[g] = t; valid_out[g] = nvalid; invalid_out[g] = ninvalid;
+        milestone_out[2 * g] = make_int4(ms[0], ms[1], ms[2], ms[3]);
+        milestone_out[2 * g + 1] = make_int4(ms[4], ms[5], ms[6], ms[7]);
         if (expanded_out) expanded_out[g] = expanded;
+        alive_out[g] = alive ? 1 : 0;
     }
 }
 
@@ -255,6 +316,38 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
         hipLaunchKernelGGL(beam_kernel<2>, grid, block, 0, s, roots, valid_mask_or_null, action_out, prob_out,
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold,
                            k.k0, k.k1, game_id_base, fd, keyblock);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+    return G2048_OK;
+}
+
+int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
+                     int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                     int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+{
+    if (n_games == 0) return G2048_OK;
+    if (!boards_inout || !score_inout || !moves_out || !valid_out || !invalid_out || !milestone_move_out || !alive_out) {
+        g2048_set_last_error_("g2048_play_games: null pointer"); return G2048_ERR_ARG;
+    }
+    if ((reinterpret_cast<uintptr_t>(boards_inout) & 15u) || (reinterpret_cast<uintptr_t>(milestone_move_out) & 15u)) {
+        g2048_set_last_error_("g2048_play_games: board / milestone arrays must be 16-byte aligned"); return G2048_ERR_ARG;
+    }
+    if (width < 1 || width > kMaxWidth || max_moves < 0 || early_threshold < 0 || mid_threshold < 0 || n_games > 0x7fffffffu ||
+        (opts & ~G2048_BEAM_FIXED_DOWN)) {
+        g2048_set_last_error_("g2048_play_games: bad width / max_moves / thresholds / opts / n_games"); return G2048_ERR_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)n_games), block(64);
+    const bool fd = (opts & G2048_BEAM_FIXED_DOWN) != 0;
+    if (width <= 16)
+        hipLaunchKernelGGL(play_kernel<1>, grid, block, 0, s, static_cast<uint4 *>(boards_inout), score_inout, moves_out, valid_out,
+                           invalid_out, reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, width,
+                           depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd);
+    else
+        hipLaunchKernelGGL(play_kernel<2>, grid, block, 0, s, static_cast<uint4 *>(boards_inout), score_inout, moves_out, valid_out,
+                           invalid_out, reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, width,
+                           depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;

@@ -28,7 +28,10 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_se
 
 def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
                          device="cuda", game_id_base=0, check_every=64, early_game_threshold=512,
-                         mid_game_threshold=1024, fixed_down=False, use_graph=True):
+                         mid_game_threshold=1024, fixed_down=False, use_graph=True, fused=True):
+    """fused=True (default): every game is played start to finish by its own wavefront in one kernel launch
+    (`g2048_play_games`). fused=False: the step-by-step loop (one beam launch + one step launch + bookkeeping per move for
+    the whole batch; with use_graph=True a captured hipGraph of one move is replayed). All three produce identical games."""
     dev = torch.device(device)
     n = int(num_games)
     t_start = time.perf_counter()
@@ -41,7 +44,13 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
     expanded_sum = torch.zeros(n, dtype=torch.int64, device=dev)
     t = 0
     graph = None
-    if use_graph:
+    if fused:
+        res = ops.play_games(env.boards, env.scores, beam_width, search_depth, max_moves, early_game_threshold,
+                             mid_game_threshold, seed, game_id_base, fixed_down)
+        alive, moves, valid_cnt, invalid_cnt = res["alive"], res["moves"], res["valid_moves"], res["invalid_moves"]
+        ms_move, expanded_sum = res["milestone_move"], res["expanded"]
+        t = max_moves
+    elif use_graph:
         # One move = [keys_advance, beam, step (in place), track], all reading their RNG keys / move index from a device
         # key block, captured once into a hipGraph and replayed per move: no per-move host work besides the replay.
         kb = ops.KeyBlock(seed, 0, dev)

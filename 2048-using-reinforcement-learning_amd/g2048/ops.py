@@ -277,6 +277,31 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     return (actions, probs, expanded) if (want_expanded or (out is not None and expanded is not None)) else (actions, probs)
 
 
+def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512, mid_threshold=1024, seed=0x2048,
+               game_id_base=0, fixed_down=False):
+    """Every game played to completion in ONE launch (beam get_action -> env step fused per game, reference
+    run_evaluation.py:48-69). boards / scores are updated in place. Returns a dict of per-game tensors:
+    moves, valid_moves, invalid_moves (int32), milestone_move (int32 (n,8), -1 = never), expanded (int64), alive (uint8)."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    _require_scores(scores)
+    n = boards.shape[0]
+    if not (1 <= int(width) <= L.BEAM_MAX_WIDTH):
+        raise ValueError("g2048: beam width must be in 1..%d" % L.BEAM_MAX_WIDTH)
+    dev = boards.device
+    out = {
+        "moves": torch.zeros(n, dtype=torch.int32, device=dev), "valid_moves": torch.zeros(n, dtype=torch.int32, device=dev),
+        "invalid_moves": torch.zeros(n, dtype=torch.int32, device=dev),
+        "milestone_move": torch.full((n, 8), -1, dtype=torch.int32, device=dev),
+        "expanded": torch.zeros(n, dtype=torch.int64, device=dev), "alive": torch.zeros(n, dtype=torch.uint8, device=dev),
+    }
+    L.call(dev, L.lib().g2048_play_games, boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
+           out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
+           out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
+           int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0,
+           L.stream_ptr(dev))
+    return out
+
+
 def selftest(device="cuda"):
     r = torch.full((1,), 0xFFFF, dtype=torch.int32, device=device)
     L.call(r.device, L.lib().g2048_selftest, r.data_ptr(), L.stream_ptr(r.device))

@@ -143,6 +143,18 @@ int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_
                         void *succ_boards_out, double *reward_out, uint8_t *done_out, uint8_t *count_out,
                         size_t n, void *stream);
 
+/* The reference's evaluation loop (run_evaluation.py:48-69, evaluate_beam_search.py:16-98) fused per game: every game
+ * (one wavefront) alternates BeamSearchAgent.get_action (no caller mask) and Game2048Env.step from boards_inout /
+ * score_inout until it is over or max_moves is reached, entirely on the device. Move t of game g uses the draws of
+ * g2048_beam_get_action(step_index = t, game id g) and g2048_step(step_index = t, board id g), so the outcome equals
+ * the step-by-step loop. Outputs per game: final board / score (in place), moves played, valid / invalid move counts,
+ * milestone_move_out[g][0..8) = move at which tiles 64..8192 first appeared (-1 = never), total children expanded
+ * (optional), alive_out[g] = 1 if the game hit max_moves without finishing. */
+int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
+                     int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
+                     uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
+                     uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream);
+
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
 int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream);

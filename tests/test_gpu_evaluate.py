@@ -110,3 +110,16 @@ def test_graph_replayed_driver_equals_plain_driver(g2048):
     for k in ("scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games", "total_expansions"):
         assert r0[k] == r1[k], k
     assert np.array_equal(r0["final_boards"], r1["final_boards"])
+
+
+def test_fused_play_games_equals_stepwise_drivers(g2048):
+    """g2048_play_games (each wavefront plays its whole game in one launch) == the step-by-step drivers."""
+    for w, d in ((6, 8), (20, 30)):
+        kw = dict(num_games=64 if w == 20 else 160, beam_width=w, search_depth=d, seed=31 + w, max_moves=700 if w == 6 else 5000,
+                  check_every=32, game_id_base=(1 << 36) + 5)
+        r0 = g2048.evaluate_beam_search(fused=False, use_graph=False, **kw)
+        r1 = g2048.evaluate_beam_search(fused=True, **kw)
+        for k in ("scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games",
+                  "total_expansions", "unfinished"):
+            assert r0[k] == r1[k], (w, k)
+        assert np.array_equal(r0["final_boards"], r1["final_boards"])
