@@ -124,3 +124,18 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert "g2048o_" not in src and "from oracle" not in src and "import oracle" not in src, f
                 assert "hostsim_" not in src and "__HIP_DEVICE_COMPILE__" not in src, f        # no host emulation inside
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/agents"), reason="needs the reference checkout (build container only)")
+def test_drop_in_import_layout_with_reference_behind():
+    """PYTHONPATH=<package dir>:<reference>: the two replaced modules come from here, the rest of the reference's
+    packages (agents.ppo_agent, which train.py imports) still resolve -- checked in a clean interpreter."""
+    import subprocess
+    import sys
+    code = ("import agents.beam_search_agent as b, environment.game_2048 as e, agents.ppo_agent as p, utils.visualization;"
+            "print(b.__file__); print(e.__file__); print(p.__file__)")
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + "/root/reference")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()[-3:]
+    assert lines[0].startswith(PKG) and lines[1].startswith(PKG) and lines[2].startswith("/root/reference")
