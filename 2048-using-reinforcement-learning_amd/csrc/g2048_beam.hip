@@ -1,21 +1,19 @@
 // g2048_beam.hip -- BeamSearchAgent.get_action (reference agents/beam_search_agent.py:71-181) on gfx950.
 //
-// One wavefront owns one game. The beam (<= 32 boards, 16 B each) lives in LDS; at every level the
-// 4 * beam children map onto the 64 lanes (two passes when 4 * width > 64), each lane doing one
-// agent move (g2048_board.h, the same SWAR code the env kernel uses), its validity, the spawn and
-// the heuristic score in registers. The only cross-lane steps are
-//   * the draw index: the reference consumes its RNG sequentially in generation order
-//     (parent rank, then action); a child's position in that sequence is a ballot prefix count,
-//     so the j-th generated child of a decision always gets draw j, exactly as the Python loop does;
-//   * the compaction of valid children: a move is tried for every (parent, action) slot, the children
-//     that changed the board are packed into LDS at their ballot-prefix index, and only those get the
-//     spawn and the heuristic -- usually one 64-lane round instead of two;
-//   * the top-k: each candidate counts the candidates that sort before it (score descending,
-//     generation order ascending = Python's stable sorted(reverse=True)) with broadcast LDS reads of
-//     the key array, and the first `width` write themselves back to the beam at their rank. On
-//     _fast_evaluate levels the score is a small integer, so (score, order) is one unique u32 key.
-// Scores are f64 in the reference's operation order (bit-exact with the oracle); no MFMA, no global
-// memory traffic inside the search (root in, action out).
+// One wavefront owns one game. The beam (<= 32 boards, 16 B each) lives in LDS. Each level has two stages:
+//   A. lane 2p + axis makes BOTH moves of one axis of parent p (g2048_board.h move_axis: one transpose in, two slides,
+//      two transposes out; the same SWAR slide the env kernel uses, plus the reference's rot180-DOWN quirk), so
+//      2 * beam <= 64 lanes cover the four moves of every parent in one round; the children that changed the board are
+//      packed into LDS at their ballot-prefix index, i.e. in the reference's generation order (parent rank, action);
+//   B. one lane per valid child: the spawn -- child j of the decision takes draw j, exactly as the Python loop
+//      consumes its RNG -- and the heuristic score, fed the empty count and max code the kernel already knows;
+//      then the top-k: each candidate counts the candidates that sort before it (score descending, generation order
+//      ascending = Python's stable sorted(reverse=True)) with broadcast LDS reads, and the first `width` write
+//      themselves back to the beam at their rank. On _fast_evaluate levels the score is a small exact integer, so
+//      (score, order) is one unique u32 key; levels 1..3 (_evaluate_state) rank f64 scores.
+// Scores are computed in the reference's operation order (bit-exact with the oracle); no MFMA, no global memory
+// traffic inside the search (root in, action out). beam_decide() is the search as a device function; beam_kernel
+// runs it once per game (g2048_beam_get_action), play_kernel loops it with the env step (g2048_play_games).
 #include <hip/hip_runtime.h>
 #include <math.h>
 
