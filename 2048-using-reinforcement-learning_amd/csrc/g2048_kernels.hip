@@ -6,6 +6,7 @@
 // No LDS, no MFMA: the work is integer SWAR on four VGPRs per board (g2048_board.h) plus ~20 f64
 // operations for the shaped reward. Compile with -ffp-contract=off (reward / eval operation order).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -238,6 +239,27 @@ __global__ __launch_bounds__(kBlock) void obs_kernel(const uint32_t *__restrict_
     const uint32_t x = rows[i];
     obs[i] = make_float4((float)(x & 0xffu) / 15.0f, (float)((x >> 8) & 0xffu) / 15.0f,
                          (float)((x >> 16) & 0xffu) / 15.0f, (float)(x >> 24) / 15.0f);
+}
+
+// the same observation rounded once more, to f16 or bf16 (round to nearest even of the f32 quotient): 8 bytes per row
+template <bool BF16>
+__global__ __launch_bounds__(kBlock) void obs16_kernel(const uint32_t *__restrict__ rows, uint2 *__restrict__ obs, size_t n_rows)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t x = rows[i];
+    uint32_t h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v = (float)((x >> (8 * k)) & 0xffu) / 15.0f;
+        if (BF16) {
+            const uint32_t u = __float_as_uint(v);
+            h[k] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;          // v is a finite non-negative number: RNE by integer add
+        } else {
+            h[k] = (uint32_t)__half_as_ushort(__float2half_rn(v));
+        }
+    }
+    obs[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
 }
 
 __global__ __launch_bounds__(kBlock) void pack_kernel(const int4 *__restrict__ tiles, uint32_t *__restrict__ rows, size_t n_rows)
@@ -556,6 +578,19 @@ int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream)
     hipLaunchKernelGGL(obs_kernel, dim3(blocks_for(n * 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint32_t *>(boards), reinterpret_cast<float4 *>(obs_out), n * 4);
     return check_launch("g2048_obs_f32");
+}
+
+int g2048_obs_16(const void *boards, void *obs_out, int bf16, size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !obs_out) return fail(G2048_ERR_ARG, "g2048_obs_16: null pointer");
+    if (!aligned16(boards) || (reinterpret_cast<uintptr_t>(obs_out) & 7u)) return fail(G2048_ERR_ARG, "g2048_obs_16: misaligned array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bf16) hipLaunchKernelGGL(obs16_kernel<true>, dim3(blocks_for(n * 4)), dim3(kBlock), 0, s, static_cast<const uint32_t *>(boards),
+                                 static_cast<uint2 *>(obs_out), n * 4);
+    else hipLaunchKernelGGL(obs16_kernel<false>, dim3(blocks_for(n * 4)), dim3(kBlock), 0, s, static_cast<const uint32_t *>(boards),
+                            static_cast<uint2 *>(obs_out), n * 4);
+    return check_launch("g2048_obs_16");
 }
 
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream)

@@ -119,9 +119,19 @@ def evaluate(boards, kind, phase=None, out=None):
     return out
 
 
-def obs(boards, out=None):
-    """PPOAgent.normalize_state for every board (agents/ppo_agent.py:184-195): float32 (n,16)."""
+def obs(boards, out=None, dtype=torch.float32):
+    """PPOAgent.normalize_state for every board (agents/ppo_agent.py:184-195): float32 (n,16); dtype=torch.float16 /
+    torch.bfloat16 give the same values rounded once more (nearest even) for reduced-precision policies."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    if out is not None:
+        dtype = out.dtype
+    if dtype in (torch.float16, torch.bfloat16):
+        if out is None:
+            out = torch.empty((boards.shape[0], 16), dtype=dtype, device=boards.device)
+        L.require_device_tensor(out, dtype, (16,), "out")
+        L.call(boards.device, L.lib().g2048_obs_16, boards.data_ptr(), out.data_ptr(), int(dtype == torch.bfloat16),
+               boards.shape[0], L.stream_ptr(boards.device))
+        return out
     if out is None:
         out = torch.empty((boards.shape[0], 16), dtype=torch.float32, device=boards.device)
     L.require_device_tensor(out, torch.float32, (16,), "out")

@@ -30,7 +30,7 @@ def masked_sample(probs, mask4, generator=None):
 
 class RolloutCollector:
     def __init__(self, n_envs, n_steps, policy, device="cuda", seed=0x2048, id_base=0, shaping=False,
-                 generator=None, sampler="fused"):
+                 generator=None, sampler="fused", obs_dtype=torch.float32):
         self.n, self.T = int(n_envs), int(n_steps)
         self.device = torch.device(device)
         self.policy = policy
@@ -41,7 +41,7 @@ class RolloutCollector:
         self.sampler = sampler
         self.env = VecGame2048(self.n, device=self.device, seed=seed, id_base=id_base, auto_reset=True)
         d, T, n = self.device, self.T, self.n
-        self.obs = torch.empty((T, n, 16), dtype=torch.float32, device=d)
+        self.obs = torch.empty((T, n, 16), dtype=obs_dtype, device=d)      # float32 (reference) or float16 / bfloat16
         self.masks = torch.empty((T, n), dtype=torch.uint8, device=d)
         self.actions = torch.empty((T, n), dtype=torch.uint8, device=d)
         self.logp = torch.empty((T, n), dtype=torch.float32, device=d)
@@ -49,7 +49,7 @@ class RolloutCollector:
         self.rewards = torch.empty((T, n), dtype=torch.float32, device=d)
         self.flags = torch.empty((T, n), dtype=torch.uint8, device=d)
         self.shaped = torch.empty((T, n), dtype=torch.float64, device=d) if shaping else None
-        self.last_obs = torch.empty((n, 16), dtype=torch.float32, device=d)
+        self.last_obs = torch.empty((n, 16), dtype=obs_dtype, device=d)
         self.env_steps = 0
 
     @torch.no_grad()

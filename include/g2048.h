@@ -106,6 +106,10 @@ int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, doubl
 /* PPOAgent.normalize_state (agents/ppo_agent.py:184-195): obs_out[i*16+j] = float32(code)/float32(15). */
 int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream);
 
+/* the same observation in 16 bits: obs_out is n*16 IEEE half (bf16 = 0) or bfloat16 (bf16 = 1) values, each the f32
+ * quotient above rounded to nearest even -- for policies that run in reduced precision (32 B per board instead of 64) */
+int g2048_obs_16(const void *boards, void *obs_out, int bf16, size_t n, void *stream);
+
 /* BeamSearchAgent.get_action for n_games roots (agents/beam_search_agent.py:71-181).
  * valid_mask_or_null: caller-supplied masks (the `valid_moves` argument), NULL = None.
  * expanded_out_or_null: children generated per game (calls of _add_random_tile).

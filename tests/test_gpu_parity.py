@@ -358,3 +358,14 @@ def test_random_action_steps_equal_explicit_actions(ops):
         b2, r2, d2, _ = e2.step()
         assert bool((b1 == b2).all()) and bool((d1 == d2).all()) and bool((e1.scores == e2.scores).all())
         assert np.array_equal(host(r1), host(r2), equal_nan=True)
+
+
+def test_obs_f16_bf16(ops, oracle):
+    """Reduced-precision observations = the reference's f32 normalize_state values rounded to nearest even."""
+    b = ops.synth_boards(200003, seed=91, p_empty=0.3, max_code=17, device=DEV)
+    f32 = torch.from_numpy(oracle.obs_batch(host(b)))
+    for dt in (torch.float16, torch.bfloat16):
+        got = ops.obs(b, dtype=dt).cpu()
+        assert got.dtype == dt and bool((got.view(torch.int16) == f32.to(dt).view(torch.int16)).all())
+    out = torch.empty((200003, 16), dtype=torch.bfloat16, device=DEV)
+    assert ops.obs(b, out=out) is out
