@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-beam", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--no-evaluation", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -207,6 +208,18 @@ def main():
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
                           "hbm_equivalent_GBs_at_29B": total_exp / bsec * BEAM_BYTES / 1e9}
+
+    # ---- evaluation leg: 4096 beam-search games (w=20, d=30) played to completion, fused per game
+    if not args.no_evaluation and not args.no_beam and world == 1:
+        from g2048 import evaluate_beam_search
+        evaluate_beam_search(256, BEAM_WIDTH, BEAM_DEPTH, seed=1, max_moves=50, device=dev)      # warm
+        ev = evaluate_beam_search(BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
+        sm = ev["summary"]
+        result["evaluation"] = {"metric": "4096 complete beam-search games (width 20, depth 30, 5000-move cap), one launch",
+                                "seconds": ev["elapsed_s"], "moves": ev["total_moves"], "moves_per_s": sm["moves_per_s"],
+                                "expansions_per_s": sm["expansions_per_s"], "rate_2048_or_more": sm["rate_2048_or_more"],
+                                "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
+                                                                                                "average_score": 18945.6}}
 
     # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions
     # drawn inside the step kernel (G2048_STEP_RANDOM_ACTIONS; realistic tile distribution instead of the synthetic
