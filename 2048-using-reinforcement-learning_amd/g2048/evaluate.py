@@ -16,6 +16,7 @@ invalid_moves, milestones, best_games, final_boards, best_board, best_score, bes
 """
 import json
 import time
+import warnings
 
 import torch
 
@@ -64,23 +65,29 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
             ops.step(env.boards, out[0], env.scores, 0, 0, game_id_base, out=env.boards, reward=env.reward, flags=env.flags,
                      keyblock=kb)
             ops.track_episodes(env.flags, alive, moves, valid_cnt, invalid_cnt, ms_move, 0, out[2], expanded_sum, keyblock=kb)
+        # The warm-up move below really executes (capture does not), so the state is snapshotted first -- on the current
+        # stream, BEFORE the side stream is made to wait for it, so the snapshot is ordered ahead of the warm-up -- and
+        # restored afterwards whether or not the capture succeeded: the loop always starts from move 0.
+        tracked = (env.boards, env.scores, alive, moves, valid_cnt, invalid_cnt, ms_move, expanded_sum, kb.counter)
+        state = [x.clone() for x in tracked]
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
         try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
             graph = torch.cuda.CUDAGraph()
-            state = [x.clone() for x in (env.boards, env.scores, alive, moves, valid_cnt, invalid_cnt, ms_move, expanded_sum,
-                                         kb.counter)]
             with torch.cuda.stream(side):
-                one_move()                      # warm-up outside capture (it also advances the state: restored below)
+                one_move()                      # warm-up outside capture
                 side.synchronize()
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     one_move()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            for dst, src in zip((env.boards, env.scores, alive, moves, valid_cnt, invalid_cnt, ms_move, expanded_sum,
-                                 kb.counter), state):
-                dst.copy_(src)                  # capture does not execute, the warm-up did: rewind to move 0
-        except Exception:                       # noqa: BLE001 -- capture unavailable: plain launches
+        except Exception as exc:                # noqa: BLE001 -- capture unavailable: plain launches, same games
+            warnings.warn("g2048.evaluate_beam_search: hipGraph capture failed (%s: %s); falling back to one launch "
+                          "sequence per move" % (type(exc).__name__, exc), RuntimeWarning, stacklevel=2)
             graph = None
+            torch.cuda.synchronize(dev)
+        cur.wait_stream(side)
+        for dst, src in zip(tracked, state):
+            dst.copy_(src)                      # rewind to move 0
     while t < max_moves:
         if graph is not None:
             graph.replay()

@@ -22,9 +22,6 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 import __graft_entry__ as ge  # noqa: E402
@@ -48,19 +45,48 @@ def parse():
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--no-evaluation", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry-launch", action="store_true", help="print the multi-GPU child command as JSON and exit")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_gpus, argv, port=None):
+    """The child command `python bench.py --gpus N` (N > 1, no torchrun environment) starts: one rank per GPU through
+    torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else _free_port()),
+            os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Parent of a multi-GPU run: it starts the ranks as a CHILD process and relays its exit code. Nothing in this
+        # process has touched (or will touch) the GPU: no torch.cuda call, no HIP library load, no exec of a process
+        # that initialised the device.
+        cmd = launch_command(args.gpus, sys.argv[1:])
+        if args.dry_launch:
+            print(json.dumps({"launch": cmd}))
+            return 0
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        return subprocess.call(cmd, env=env)
+    if args.dry_launch:
+        print(json.dumps({"launch": None}))
+        return 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world           # under torchrun the environment is authoritative
+    global np, torch            # imported here, not at module level: the launcher parent above needs neither
+    import numpy as np
+    import torch
     ndev = max(torch.cuda.device_count(), 1)
     local_dev = local_rank % ndev            # normally local_rank; a 2-rank rehearsal on one GPU shares cuda:0
     torch.cuda.set_device(local_dev)
@@ -150,6 +176,18 @@ def main():
         assert gathered.numel() == world * n and bool((gathered[rank * n:(rank + 1) * n] == scores).all())
         m = gdist.reduce_metrics(ops.metrics(out, scores, flags))
         assert int(m[0].item()) == world * n
+        if rank == 0:
+            # the gathered vector must equal what ONE GPU computes for the same global ids: rank 0 re-runs the K timed
+            # steps of every other shard (same seed, step indices and id_base = shard start) and compares
+            vb, va = torch.empty_like(boards), torch.empty_like(actions)
+            vo, vs = torch.empty_like(boards), torch.empty_like(scores)
+            for r in range(1, world):
+                ops.synth_boards(n, seed=SEED, id_base=r * n, device=dev, out=vb)
+                ops.synth_actions(n, seed=SEED, step_index=0, id_base=r * n, device=dev, out=va)
+                vs.zero_()
+                for t in range(K):
+                    ops.step(vb, va, vs, SEED, W + t, r * n, out=vo, reward=reward, flags=flags)
+                assert bool((gathered[r * n:(r + 1) * n] == vs).all()), "shard %d differs from the 1-GPU result" % r
 
     # ---- roofline: algorithmic bytes per launch / average launch duration over the timed region ----
     achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
@@ -180,7 +218,11 @@ def main():
                      "timing": "HIP event pair on the launch stream around the K timed launches / K"},
     }
     if gather_ms is not None:
+        import torch.distributed as tdist
         result["allgather_scores_ms"] = gather_ms
+        result["n_ranks_seen"] = tdist.get_world_size()
+        result["backend"] = tdist.get_backend()
+        result["gathered_equals_single_gpu"] = True        # asserted above on rank 0
 
     # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
     if not args.no_beam:
@@ -346,4 +388,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
