@@ -73,7 +73,13 @@ G2048_HD uint32_t count_empty(const Board &b)
 
 G2048_HD bool same(const Board &a, const Board &b)
 {
-    return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) == 0;
+    uint32_t d = (a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3]);
+#if defined(__HIPCC__)
+    // keep this ONE integer test: left to itself the compiler sometimes turns it into four compares whose results it
+    // then packs bit by bit with 16-bit shifts and ors (11 VALU instructions instead of 6)
+    asm volatile("" : "+v"(d));
+#endif
+    return d == 0;
 }
 
 // 4x4 byte transpose: 2 x 4 v_perm_b32
@@ -178,6 +184,41 @@ G2048_HD Board move_env(const Board &b, uint32_t action, uint32_t &gain)
 {
     uint32_t merges;
     return move_env(b, action, gain, merges);
+}
+
+// ---- direction by table -----------------------------------------------------------------------------------------
+// The same move with the direction handled by ONE two-stage v_perm network whose four byte selectors are per-lane
+// data instead of per-lane selects between a transposed and an untransposed, a reversed and an unreversed copy:
+//   stage 1 pairs rows (0,2) and (1,3):  u0 = perm(x2,x0,a)  u1 = perm(x2,x0,b)  u2 = perm(x3,x1,a)  u3 = perm(x3,x1,b)
+//   stage 2 pairs (u0,u2) and (u1,u3):   y0 = perm(u2,u0,c)  y1 = perm(u2,u0,d)  y2 = perm(u3,u1,c)  y3 = perm(u3,u1,d)
+// With (a,b,c,d) = (lo,hi,lo,hi) the network is the identity, with (hi,lo,hi,lo) it reverses the word order, with the
+// interleaving selectors it transposes (this pairing, unlike transpose() above, can also pass words through), and
+// RIGHT folds its byte reversal into stage 1. Eight words per action: rows -> lines, then lines -> rows (the same
+// four for LEFT / UP / DOWN, whose maps are involutions). 16 v_perm per move, no v_cndmask; the kernels keep the
+// table in LDS and fetch a lane's eight words with two ds_read_b128 (derivation: tools/dirnet.py).
+struct DirSel { uint32_t a, b, c, d, oa, ob, oc, od; };
+
+#define G2048_DIR_TABLE_WORDS 32
+#define G2048_DIR_TABLE_INIT { \
+    /* 0 LEFT  */ 0x05040100u, 0x07060302u, 0x06020400u, 0x07030501u,   0x05040100u, 0x07060302u, 0x06020400u, 0x07030501u, \
+    /* 1 UP    */ 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u,   0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, \
+    /* 2 RIGHT */ 0x07060302u, 0x05040100u, 0x07030501u, 0x06020400u,   0x05040100u, 0x07060302u, 0x00040206u, 0x01050307u, \
+    /* 3 DOWN  */ 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u,   0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u }
+
+G2048_HD void dir_net(const uint32_t x[4], uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t y[4])
+{
+    const uint32_t u0 = perm(x[2], x[0], a), u1 = perm(x[2], x[0], b), u2 = perm(x[3], x[1], a), u3 = perm(x[3], x[1], b);
+    y[0] = perm(u2, u0, c); y[1] = perm(u2, u0, d); y[2] = perm(u3, u1, c); y[3] = perm(u3, u1, d);
+}
+
+G2048_HD Board move_env_sel(const Board &b, const DirSel &s, uint32_t &gain, uint32_t &merges)
+{
+    uint32_t L[4];
+    dir_net(b.w, s.a, s.b, s.c, s.d, L);
+    gain = slide_lines(L, merges);
+    Board o;
+    dir_net(L, s.oa, s.ob, s.oc, s.od, o.w);
+    return o;
 }
 
 // Both moves of one axis at once (beam kernel): vertical = (UP, DOWN), horizontal = (LEFT, RIGHT). One transpose in,
@@ -379,6 +420,28 @@ G2048_HD uint32_t max_code(const Board &b)
 // :200-203) -- with max(prev_board); the two are always equal inside step(), so
 // the branch is dead there and is not generated. `cur` is the post-spawn board.
 // Must be compiled with -ffp-contract=off (the 0.1 terms are mul THEN add).
+// edge / total of the reward as an IEEE-754 correctly rounded f64 quotient without the generic division's range
+// handling: both operands are integers below 2^23 (exact in f64, no overflow / underflow / denormal is reachable), so
+// the scaling (v_div_scale_f64 x2) and the special-case fix-up (v_div_fixup_f64) of the compiler's expansion are
+// no-ops here and what remains is that expansion itself: v_rcp_f64, two Newton steps, quotient, residual, final fma.
+// 0 / 0 (the degenerate all-empty board) gives NaN as a / b does: rcp(0) = inf, fma(-0, inf, 1) = NaN.
+// tools/ubench/div_check.hip compares it with a / b over every operand pair of a range on the device.
+G2048_HD double div_small_ints(double a, double b)
+{
+#if defined(__HIPCC__)
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+#else
+    return a / b;
+#endif
+}
+
 G2048_HD double reward_env_from(double r, const Board &cur, const TileStats &st, bool valid,
                                 uint32_t empty_before, uint32_t empty_after)
 {
@@ -416,7 +479,7 @@ G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_
 {
     const int32_t q = (int32_t)gain - (valid ? 0 : 8) + 2 * ((int32_t)empty_after - (int32_t)empty_before);
     double r = (double)q * 0.25;
-    r += ((double)st.edge / (double)st.total) * 1.0;
+    r += div_small_ints((double)st.edge, (double)st.total) * 1.0;
     if (empty_after <= 2u) r -= 2.0;
     const uint32_t n0 = nzflag(cur.w[0]), n1 = nzflag(cur.w[1]), n2 = nzflag(cur.w[2]), n3 = nzflag(cur.w[3]);
     const uint32_t v01 = geflag(cur.w[1], cur.w[0]) & n0 & n1;
@@ -448,11 +511,13 @@ G2048_HD bool game_over_counted(const Board &b, uint32_t n_empty)
 // (:201-203, always the current max inside step()). h is the board's 32-bit draw for this step.
 struct StepOut { Board board; uint32_t gain; double reward; uint32_t flags; };
 
-G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
+// MOVE: a callable (const Board &, uint32_t &gain, uint32_t &merges) -> Board doing the env move
+template <class MOVE>
+G2048_HD StepOut step_board_with(const Board &prev, MOVE move, uint32_t h)
 {
     StepOut o;
     uint32_t merges;
-    Board cur = move_env(prev, action, o.gain, merges);
+    Board cur = move(prev, o.gain, merges);
     const bool valid = !same(cur, prev);
     uint32_t empty_mid;                 // empties of the moved board, before the spawn
     uint32_t zf[4];                     // zero flags of the post-spawn board
@@ -468,6 +533,17 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
     o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);
     o.board = cur;
     return o;
+}
+
+G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
+{
+    return step_board_with(prev, [action](const Board &b, uint32_t &g, uint32_t &m) { return move_env(b, action, g, m); }, h);
+}
+
+// the same step with the direction given as its selector words (see "direction by table")
+G2048_HD StepOut step_board_sel(const Board &prev, const DirSel &sel, uint32_t h)
+{
+    return step_board_with(prev, [&sel](const Board &b, uint32_t &g, uint32_t &m) { return move_env_sel(b, sel, g, m); }, h);
 }
 
 // ---------------------------------------------------------------- policy ------

@@ -46,6 +46,24 @@ constexpr int kBlock = 256;
 constexpr int kStepBoardsPerLane = 1;     // default of g2048_step: measured fastest (profiles/r01_step_tune.txt)
 inline unsigned blocks_for(size_t n, int per_block = kBlock) { return (unsigned)((n + per_block - 1) / per_block); }
 
+// selector words of the direction network (g2048_board.h, "direction by table"); every wave copies them into the
+// block's LDS table itself -- all waves write the same 32 words, and a wave's own write precedes its reads in its
+// LDS queue, so no block barrier is needed -- and a lane then fetches the eight words of its action with two
+// ds_read_b128.
+__device__ const uint32_t kDirTable[G2048_DIR_TABLE_WORDS] = G2048_DIR_TABLE_INIT;
+
+__device__ __forceinline__ void dir_table_to_lds(uint4 *s_dir)
+{
+    const uint32_t l = threadIdx.x & 63u;
+    if (l < G2048_DIR_TABLE_WORDS) reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];
+}
+
+__device__ __forceinline__ DirSel dir_sel(const uint4 *s_dir, uint32_t action)
+{
+    const uint4 i = s_dir[2u * action], o = s_dir[2u * action + 1u];
+    return DirSel{i.x, i.y, i.z, i.w, o.x, o.y, o.z, o.w};
+}
+
 __device__ __forceinline__ Board load_board(const uint4 *p, size_t i)
 {
     const uint4 v = p[i];
@@ -75,6 +93,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                                                      uint32_t a0 = 0, uint32_t a1 = 0)
 {
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
+    __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
+    dir_table_to_lds(s_dir);
     // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
     const size_t block0 = (size_t)blockIdx.x * (BLOCK * B);
     const uint4 *bin = boards_in + block0;
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         if (!(full || j < lim)) break;
         const uint64_t id = id_base + block0 + j;
         if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
-        const StepOut o = step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id, 0u));
+        const StepOut o = step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u));
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
         if (AUTO_RESET) {

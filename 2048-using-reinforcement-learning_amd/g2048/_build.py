@@ -12,7 +12,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB = os.environ.get("G2048_LIB") or os.path.join(CSRC, "libg2048_hip.so")     # G2048_LIB: A/B builds only (tools/)
-SOURCES = ["g2048_kernels.hip", "g2048_beam.hip"]
+SOURCES = ["g2048_kernels.hip", "g2048_beam.hip", "g2048_rollout.hip"]
 HEADERS = ["g2048_board.h", "g2048_rng.h", os.path.join("..", "..", "include", "g2048.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]

@@ -19,8 +19,11 @@ STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS = 0x01, 0x02, 0x04
 VALID_ENV, VALID_AGENT = 0, 1
 EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING = range(8)
 BEAM_FIXED_DOWN = 0x01
-BEAM_MAX_WIDTH = 32
+BEAM_ONE_WAVE_PER_GAME = 0x02
+BEAM_MAX_WIDTH = 128
 KEYBLOCK_WORDS = 16
+ROLLOUT_OBS_SHIFT, OBS_F32, OBS_F16, OBS_BF16 = 4, 0, 1, 2
+SEEN_SLOT_BYTES = 32
 
 _vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {
@@ -49,6 +52,12 @@ SIGNATURES = {
     "g2048_sample_actions_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _sz, _vp]),
     "g2048_track_episodes_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "g2048_selftest": (_int, [_vp, _vp]),
+    "g2048_rollout_step": (_int, [_vp] * 13 + [_u64, _u64, _vp, _u64, _sz, _u32, _vp]),
+    "g2048_shaping_scan_workspace": (_sz, [_sz]),
+    "g2048_shaping_scan": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2048_seen_insert": (_int, [_vp, _u64, _vp, _u32, _vp, _vp, _vp, _sz, _vp]),
+    "g2048_seen_rehash": (_int, [_vp, _u32, _vp, _u32, _vp, _vp]),
+    "g2048_shaping_apply": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -185,6 +185,128 @@ def sample_actions(probs, mask4=None, seed=0x2048, step_index=0, id_base=0, acti
     return actions, prob
 
 
+_OBS_KIND = {torch.float32: L.OBS_F32, torch.float16: L.OBS_F16, torch.bfloat16: L.OBS_BF16}
+
+
+def rollout_step(boards, probs, scores, seed, step_index, id_base=0, *, mask=None, out=None, actions=None, prob=None,
+                 reward=None, flags=None, obs_next=None, mask_next=None, next_boards=None, state_maxcode=None,
+                 auto_reset=True, step_counter=None):
+    """One PPO rollout step of every env in ONE launch (include/g2048.h, g2048_rollout_step): masked sampling from
+    `probs` (agents/ppo_agent.py:211-221) -> Game2048Env.step (environment/game_2048.py:170-210) -> next observation
+    (ppo_agent.py:184-195, dtype of `obs_next`) and next valid-move mask (game_2048.py:69-95), all from registers.
+    reward may be float32 or float64. step_counter: int64 device tensor added to step_index inside the kernel (for
+    replayable hipGraphs). Returns (boards_out, actions, prob, reward, flags)."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    L.require_device_tensor(probs, torch.float32, (4,), "probs")
+    _require_scores(scores)
+    n, dev = boards.shape[0], boards.device
+    if probs.shape[0] != n or scores.shape[0] != n:
+        raise ValueError("g2048: probs/scores length must equal the number of boards")
+    out = torch.empty_like(boards) if out is None else L.require_device_tensor(out, torch.uint8, (16,), "out")
+    actions = torch.empty(n, dtype=torch.uint8, device=dev) if actions is None else L.require_device_tensor(actions, torch.uint8, None, "actions")
+    prob = torch.empty(n, dtype=torch.float32, device=dev) if prob is None else L.require_device_tensor(prob, torch.float32, None, "prob")
+    if reward is None:
+        reward = torch.empty(n, dtype=torch.float32, device=dev)
+    if reward.dtype not in (torch.float32, torch.float64):
+        raise TypeError("g2048: reward must be float32 or float64")
+    L.require_device_tensor(reward, reward.dtype, None, "reward")
+    flags = torch.empty(n, dtype=torch.uint8, device=dev) if flags is None else L.require_device_tensor(flags, torch.uint8, None, "flags")
+    opts = (L.STEP_REWARD_F64 if reward.dtype == torch.float64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0)
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    if mask is not None:
+        L.require_device_tensor(mask, torch.uint8, None, "mask")
+    if obs_next is not None:
+        if obs_next.dtype not in _OBS_KIND:
+            raise TypeError("g2048: obs_next must be float32, float16 or bfloat16")
+        L.require_device_tensor(obs_next, obs_next.dtype, (16,), "obs_next")
+        opts |= _OBS_KIND[obs_next.dtype] << L.ROLLOUT_OBS_SHIFT
+    if mask_next is not None:
+        L.require_device_tensor(mask_next, torch.uint8, None, "mask_next")
+    if next_boards is not None:
+        L.require_device_tensor(next_boards, torch.uint8, (16,), "next_boards")
+    if state_maxcode is not None:
+        L.require_device_tensor(state_maxcode, torch.uint8, None, "state_maxcode")
+    if step_counter is not None:
+        L.require_device_tensor(step_counter, torch.int64, None, "step_counter")
+    for name, t in (("actions", actions), ("prob", prob), ("reward", reward), ("flags", flags), ("out", out), ("mask", mask),
+                    ("obs_next", obs_next), ("mask_next", mask_next), ("next_boards", next_boards), ("state_maxcode", state_maxcode)):
+        if t is not None and t.shape[0] != n:
+            raise ValueError("g2048: %s must have one row per env" % name)
+    L.call(dev, L.lib().g2048_rollout_step, boards.data_ptr(), probs.data_ptr(), ptr(mask), out.data_ptr(), scores.data_ptr(),
+           actions.data_ptr(), prob.data_ptr(), reward.data_ptr(), flags.data_ptr(), ptr(obs_next), ptr(mask_next),
+           ptr(next_boards), ptr(state_maxcode), L.u64(seed), L.u64(step_index), ptr(step_counter), L.u64(id_base), n, opts,
+           L.stream_ptr(dev))
+    return out, actions, prob, reward, flags
+
+
+class SeenStates:
+    """The `seen_states` set and `highest_tile_seen` of PPOAgent (agents/ppo_agent.py:171-176) for ordered batches of
+    transitions, resident on the GPU: an open-addressing hash set keyed by the 16-byte board (include/g2048.h,
+    g2048_seen_insert) that grows by rehashing, the running highest log2 code, and the running transition index."""
+
+    def __init__(self, device="cuda", capacity_log2=20):
+        self.device = torch.device(device)
+        self.capacity_log2 = int(capacity_log2)
+        self.table = torch.zeros((1 << self.capacity_log2, L.SEEN_SLOT_BYTES), dtype=torch.uint8, device=self.device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.highest = torch.ones(1, dtype=torch.int32, device=self.device)     # log2 code of tile 2 (ppo_agent.py:171)
+        self.index = 0              # transitions presented so far (global order)
+
+    def reserve(self, n_new):
+        """Grow (rehash into a zeroed table twice the size, repeatedly) until count + n_new keys keep it at most half
+        full. Reads the key count back from the device (one host sync)."""
+        if int(self.overflow.item()):
+            raise RuntimeError("g2048: the seen-states table overflowed (it is sized by reserve(); was it bypassed?)")
+        need = int(self.count.item()) + int(n_new)
+        log2 = self.capacity_log2
+        while (1 << log2) < 2 * need:
+            log2 += 1
+        if log2 != self.capacity_log2:
+            if log2 > 31:
+                raise RuntimeError("g2048: seen-states table would exceed 2^31 slots")
+            new = torch.zeros((1 << log2, L.SEEN_SLOT_BYTES), dtype=torch.uint8, device=self.device)
+            L.call(self.device, L.lib().g2048_seen_rehash, self.table.data_ptr(), self.capacity_log2, new.data_ptr(), log2,
+                   self.overflow.data_ptr(), L.stream_ptr(self.device))
+            self.table, self.capacity_log2 = new, log2
+
+    def __len__(self):
+        return int(self.count.item())
+
+
+def remember_shaping(seen, next_boards, state_maxcode, flags, env_reward, out=None, want_novel=False):
+    """PPOAgent.remember's stored reward (agents/ppo_agent.py:234-269) for an ORDERED batch of transitions, with the
+    reference's sequential semantics for both stateful terms, continuing from `seen` (a SeenStates). Inputs are flat in
+    order: next_boards uint8 (n,16) -- the next state BEFORE any auto-reset --, state_maxcode uint8 (n,), flags uint8 (n,)
+    as the step wrote them, env_reward float64 (n,). Returns shaped float64 (n,) [, novel uint8 (n,)]."""
+    L.require_device_tensor(next_boards, torch.uint8, (16,), "next_boards")
+    n, dev = next_boards.shape[0], next_boards.device
+    L.require_device_tensor(state_maxcode, torch.uint8, None, "state_maxcode")
+    L.require_device_tensor(flags, torch.uint8, None, "flags")
+    L.require_device_tensor(env_reward, torch.float64, None, "env_reward")
+    if not (state_maxcode.shape[0] == flags.shape[0] == env_reward.shape[0] == n):
+        raise ValueError("g2048: all transition arrays must have the same length")
+    if out is None:
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+    L.require_device_tensor(out, torch.float64, None, "out")
+    if n == 0:
+        return (out, torch.empty(0, dtype=torch.uint8, device=dev)) if want_novel else out
+    seen.reserve(n)
+    lib, st = L.lib(), L.stream_ptr(dev)
+    ws = torch.empty(int(lib.g2048_shaping_scan_workspace(n)), dtype=torch.uint8, device=dev)
+    prev_highest = torch.empty(n, dtype=torch.uint8, device=dev)
+    slots = torch.empty(n, dtype=torch.int32, device=dev)
+    novel = torch.empty(n, dtype=torch.uint8, device=dev) if want_novel else None
+    L.call(dev, lib.g2048_shaping_scan, flags.data_ptr(), prev_highest.data_ptr(), seen.highest.data_ptr(), ws.data_ptr(), n, st)
+    L.call(dev, lib.g2048_seen_insert, next_boards.data_ptr(), L.u64(seen.index), seen.table.data_ptr(), seen.capacity_log2,
+           seen.count.data_ptr(), seen.overflow.data_ptr(), slots.data_ptr(), n, st)
+    L.call(dev, lib.g2048_shaping_apply, next_boards.data_ptr(), state_maxcode.data_ptr(), flags.data_ptr(), env_reward.data_ptr(),
+           prev_highest.data_ptr(), seen.table.data_ptr(), slots.data_ptr(), L.u64(seen.index), out.data_ptr(),
+           novel.data_ptr() if novel is not None else None, n, st)
+    seen.index += n
+    return (out, novel) if want_novel else out
+
+
 def simulate_move(boards, actions, highest_code=None):
     """Game2048Env.simulate_move for every (board, action) (environment/game_2048.py:341-387).
     Returns (succ uint8 (n,32,16), reward float64 (n,32), done bool (n,32), count uint8 (n,)); only the first
@@ -258,7 +380,7 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
                     seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
-                    out=None):
+                    out=None, one_wave_per_game=False):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
     Returns (actions uint8, probs float32[, expanded int32])."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
@@ -279,7 +401,8 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     head = (roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None, actions.data_ptr(), probs.data_ptr(),
             expanded.data_ptr() if expanded is not None else None, int(width), int(depth), int(early_threshold),
             int(mid_threshold))
-    tail = (L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0, L.stream_ptr(dev))
+    tail = (L.u64(game_id_base), n, (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.BEAM_ONE_WAVE_PER_GAME if one_wave_per_game else 0),
+            L.stream_ptr(dev))
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
     else:

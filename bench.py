@@ -8,11 +8,16 @@ and writing a separate output buffer so every step does identical work. With N G
 own contiguous shard of 1,048,576 boards (global ids rank*1,048,576 ..., weak scaling, config 5); the only
 collective is the final all-gather of per-board scores over RCCL, issued after the timed region.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts its own N ranks: the parent builds a
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>` command, runs it as a CHILD process
+and relays its exit code; the parent itself never touches the GPU (no torch import, no HIP call).
+
 Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs, max over ranks.
-The K launches are replayed from one hipGraph (launch-bound otherwise: a step is ~10-20 us of GPU time);
-pass --no-graph for eager launches. The roofline leg times the same kernel launch by launch with HIP
-events on the launch stream; the cpu_baseline leg times the CPU oracle (the C port of the reference
-algorithm, OpenMP over boards) on a bounded sample of the same workload, rank 0 at N = 1 only.
+The K launches are replayed from one hipGraph (launch-bound otherwise: a step is ~10-15 us of GPU time);
+pass --no-graph for eager launches. The roofline leg is the same K launches: a HIP event pair recorded INSIDE the graph
+(first and last node, on the launch stream), so that the graph's host-side launch latency -- which at K = 20 is a
+visible share of the wall clock -- is not billed to the kernel. The cpu_baseline leg times the CPU oracle (the C port of
+the reference algorithm) on a bounded sample of the same workload, rank 0 at N = 1 only.
 
 One JSON line on stdout (rank 0).
 """
@@ -27,11 +32,13 @@ sys.path.insert(0, REPO)
 import __graft_entry__ as ge  # noqa: E402
 
 BOARDS_PER_GPU = 1 << 20
+BIG_BOARDS = 1 << 24         # beyond the 256 MiB Infinity Cache: 16 Mi boards = 738 MB of streams per launch
 SEED = 0x2048
 STEP_BYTES_F32 = 46          # R board 16 + action 1 + score 4; W board 16 + score 4 + reward 4 + flags 1
+STEP_BYTES_F64 = 50          # the same with the f64 reward (parity mode)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH = 4096, 20, 30
-BEAM_BYTES = 29              # SURVEY 8(d) HBM-resident-beam accounting per expansion
+N_SIMD, CLOCK_GHZ = 1024, 2.4
 
 
 def parse():
@@ -44,7 +51,8 @@ def parse():
     ap.add_argument("--no-beam", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--no-evaluation", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the HBM-resident and f64-reward step legs")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--dry-launch", action="store_true", help="print the multi-GPU child command as JSON and exit")
     return ap.parse_args()
 
@@ -62,6 +70,74 @@ def launch_command(n_gpus, argv, port=None):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
             "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else _free_port()),
             os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+
+
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+
+
+def graph_of(fn, dev, with_events=True):
+    """Capture fn() into a hipGraph on a side stream (thread_local capture mode: with a process group alive the RCCL
+    watchdog thread issues event queries that would invalidate a global-mode capture). Returns (graph, ev0, ev1) where the
+    two events are recorded as the first and the last node of the graph (None if this torch / HIP cannot record timing
+    events inside a capture); (None, None, None) if capture is unavailable."""
+    ev0 = ev1 = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        if with_events:
+            ev0 = torch.cuda.Event(enable_timing=True, external=True)
+            ev1 = torch.cuda.Event(enable_timing=True, external=True)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                if ev0 is not None:
+                    ev0.record(side)
+                fn()
+                if ev1 is not None:
+                    ev1.record(side)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        return graph, ev0, ev1
+    except Exception as exc:            # noqa: BLE001
+        print("bench.py: hipGraph capture failed%s (%s: %s)" % (" with in-graph events" if with_events else "",
+                                                                type(exc).__name__, exc), file=sys.stderr)
+        torch.cuda.synchronize()
+        if with_events:                 # retry without in-graph events before giving the graph up
+            return graph_of(fn, dev, with_events=False)
+        return None, None, None
+
+
+def timed_replay(graph, ev0, ev1, eager, reps=1):
+    """GPU time of one replay (ms), best of `reps`: in-graph events if there are any, else an event pair around the launch."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(reps):
+        a.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            eager()
+        b.record()
+        torch.cuda.synchronize()
+        ms = None
+        if graph is not None and ev0 is not None:
+            try:
+                ms = ev0.elapsed_time(ev1)
+            except Exception:           # noqa: BLE001
+                ms = None
+        if ms is None:
+            ms = a.elapsed_time(b)
+        best = ms if best is None else min(best, ms)
+    return best
 
 
 def main():
@@ -113,55 +189,55 @@ def main():
         ops.step(boards, actions, scores, SEED, t, id_base, out=out, reward=reward, flags=flags)
 
     barrier = gdist.barrier
-
     K, W = args.steps, args.warmup
     for t in range(W):
         one_step(t)
     torch.cuda.synchronize()
 
-    graph = None
+    def k_steps():
+        for t in range(K):
+            one_step(W + t)
+
+    graph = ev0 = ev1 = None
     if not args.no_graph:
-        # thread_local capture mode: with a process group alive, the RCCL watchdog thread issues event queries
-        # that would invalidate a global-mode capture. If capture fails for any reason, fall back to eager.
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                    for t in range(K):
-                        one_step(W + t)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize()
-            for _ in range(max(3, -(-600 // K))):   # untimed: the first replay pays the graph's one-time upload, and
-                graph.replay()                      # ~10 ms of load bring the clocks to their steady state
-            torch.cuda.synchronize()
-        except Exception as exc:            # noqa: BLE001
-            print("bench.py: hipGraph capture failed (%s); timing eager launches" % exc, file=sys.stderr)
-            graph = None
+        graph, ev0, ev1 = graph_of(k_steps, dev)
+    if graph is not None:
+        # untimed: the first replay pays the graph's one-time upload, and ~20 ms of load bring the clocks to steady state
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.02:
+            graph.replay()
             torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps -------------------------------------------------
-    # wall clock between barrier + synchronize pairs (-> value), and a HIP event pair on the launch
-    # stream around the same K launches (-> average launch duration for the roofline)
+    # wall clock between barrier + synchronize pairs (-> value); the HIP events bracket the same K launches on the launch
+    # stream (-> average launch duration for the roofline)
     scores.zero_()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()
+    o0.record()
     if graph is not None:
         graph.replay()
     else:
-        for t in range(K):
-            one_step(W + t)
-    ev1.record()
+        k_steps()
+    o1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0      # this rank's K steps are complete here ...
     barrier()
     torch.cuda.synchronize()
-    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / K
+    outer_ms = o0.elapsed_time(o1)
+    timing = "HIP event pair on the launch stream around the K timed launches / K"
+    kernel_s = outer_ms * 1e-3 / K
+    if graph is not None and ev0 is not None:
+        try:
+            kernel_s = ev0.elapsed_time(ev1) * 1e-3 / K
+            timing = ("HIP events recorded inside the hipGraph (first and last node, launch stream) around the K timed "
+                      "launches / K; the pair around the graph launch, host launch latency included, gave %.3f us"
+                      % (outer_ms * 1e3 / K))
+        except Exception as exc:        # noqa: BLE001
+            print("bench.py: in-graph events unusable (%s)" % exc, file=sys.stderr)
     elapsed = gdist.max_over_ranks(elapsed, dev)    # ... and the job's time is the slowest rank's
 
     # ---- final metrics reduction: all-gather of per-board scores (config 5), timed separately
@@ -191,10 +267,12 @@ def main():
 
     # ---- roofline: algorithmic bytes per launch / average launch duration over the timed region ----
     achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
-    traffic = None
+    traffic = traffic_src = None
     pmc = os.path.join(REPO, "profiles", "pmc_step.json")     # HBM bytes per launch from the rocprofv3 PMC passes
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        pj = json.load(open(pmc))
+        traffic = pj.get("hbm_bytes_per_launch")
+        traffic_src = "recorded rocprofv3 PMC passes (%s), not an observation of this run" % pj.get("source", "profiles/pmc_step.json")
 
     result = {
         "metric": "board-steps/sec (batched env.step)",
@@ -210,12 +288,14 @@ def main():
         "config": {"workload": "BASELINE configs[1]: batched env.step, 1,048,576 random boards per GPU "
                                "(p_empty=0.30, codes 1..11), 4 actions per launch, input->output buffers",
                    "boards_per_gpu": n, "launch": "hipGraph of K launches" if graph is not None else "eager",
+                   "working_set": "48 MB per launch, re-used by every launch: resident in the 256 MiB Infinity Cache (LLC), "
+                                  "not streamed from HBM -- see roofline_hbm_resident for the beyond-LLC size",
                    "parallelism": "%d shard(s) of 1,048,576 boards, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "step_kernel<false,false,1>", "kernel_us": kernel_s * 1e6,
-                     "algorithmic_bytes_per_launch": n * STEP_BYTES_F32,
-                     "timing": "HIP event pair on the launch stream around the K timed launches / K"},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "step_kernel<false,false,1,256>", "kernel_us": kernel_s * 1e6,
+                     "algorithmic_bytes_per_launch": n * STEP_BYTES_F32, "timing": timing,
+                     "note": "LLC-resident working set at this size; the kernel is VALU-issue bound (DESIGN.md 3)"},
     }
     if gather_ms is not None:
         import torch.distributed as tdist
@@ -223,6 +303,49 @@ def main():
         result["n_ranks_seen"] = tdist.get_world_size()
         result["backend"] = tdist.get_backend()
         result["gathered_equals_single_gpu"] = True        # asserted above on rank 0
+
+    # ---- extra step legs: f64-reward parity mode at configs[1]; a working set beyond the Infinity Cache -----------
+    if not args.no_extra:
+        reward64 = torch.empty(n, dtype=torch.float64, device=dev)
+
+        def k_steps_f64():
+            for t in range(K):
+                ops.step(boards, actions, scores, SEED, W + t, id_base, out=out, reward=reward64, flags=flags, reward_f64=True)
+        k_steps_f64()
+        g64, a64, b64 = (None, None, None) if args.no_graph else graph_of(k_steps_f64, dev)
+        ms = timed_replay(g64, a64, b64, k_steps_f64, reps=3)
+        us = ms * 1e3 / K
+        result["roofline_f64_reward"] = {"bound": "hbm", "achieved": n * STEP_BYTES_F64 / us / 1e3, "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": n * STEP_BYTES_F64 / us / 1e3 / HBM_PEAK_GBS, "kernel_us": us,
+                                         "kernel": "step_kernel<true,false,1,256>", "bytes_per_board": STEP_BYTES_F64,
+                                         "board_steps_per_s": n / us * 1e6,
+                                         "note": "bit-exact parity mode: reward written as f64 (50 B per board-step)"}
+        del reward64, g64
+        nb = BIG_BOARDS
+        bb = ops.synth_boards(nb, seed=SEED + 7, id_base=id_base, device=dev)
+        ba = ops.synth_actions(nb, seed=SEED + 7, step_index=0, id_base=id_base, device=dev)
+        bo = torch.empty_like(bb)
+        bs = torch.zeros(nb, dtype=torch.int32, device=dev)
+        br = torch.empty(nb, dtype=torch.float32, device=dev)
+        bf = torch.empty(nb, dtype=torch.uint8, device=dev)
+        KB = 10
+
+        def big_steps():
+            for t in range(KB):
+                ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
+        big_steps()
+        gb, ab, bb2 = (None, None, None) if args.no_graph else graph_of(big_steps, dev)
+        ms = timed_replay(gb, ab, bb2, big_steps, reps=2)
+        us = ms * 1e3 / KB
+        result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
+                                           "kernel_us": us, "boards_per_launch": nb,
+                                           "algorithmic_bytes_per_launch": nb * STEP_BYTES_F32,
+                                           "board_steps_per_s": nb / us * 1e6,
+                                           "note": "16,777,216 boards per launch: 738 MB of streams, beyond the 256 MiB "
+                                                   "Infinity Cache, so reads come from and writes go to HBM3E"}
+        del bb, ba, bo, bs, br, bf, gb
+        torch.cuda.empty_cache()
 
     # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
     if not args.no_beam:
@@ -249,7 +372,22 @@ def main():
                           "value": total_exp / bsec, "unit": "expansions/s",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
-                          "hbm_equivalent_GBs_at_29B": total_exp / bsec * BEAM_BYTES / 1e9}
+                          "kernel": "beam_shared_kernel (4 games per 256-thread block)"}
+        # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
+        # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
+        # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
+        pb = os.path.join(REPO, "profiles", "pmc_beam.json")
+        if os.path.exists(pb):
+            pj = json.load(open(pb))
+            insts = float(pj["valu_wave_instructions_per_launch"])
+            cyc = float(pj["issue_cycles_per_instruction"])
+            peak = N_SIMD * CLOCK_GHZ / cyc             # G wave-instructions / s
+            ach = insts / (bsec / breps) / 1e9
+            result["beam"]["roofline"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+                                          "frac": ach / peak, "valu_wave_instructions_per_launch": insts,
+                                          "issue_cycles_per_instruction": cyc,
+                                          "source": "instruction count from a recorded rocprofv3 SQ_INSTS_VALU pass (%s); "
+                                                    "time measured in this run" % pj.get("source", "profiles/pmc_beam.json")}
 
     # ---- evaluation leg: 4096 beam-search games (w=20, d=30) played to completion, fused per game
     if not args.no_evaluation and not args.no_beam and world == 1:
@@ -269,37 +407,16 @@ def main():
     if not args.no_rollout:
         rb, rs = ops.reset(n, SEED, 0, id_base, device=dev)
 
-        def rollout_steps(t0):
+        def rollout_steps(t0=128):
             for t in range(t0, t0 + 128):
                 ops.step(rb, None, rs, SEED, t, id_base, out=rb, reward=reward, flags=flags, auto_reset=True)
         rollout_steps(0)
         torch.cuda.synchronize()
-        rg = None
-        try:
-            side2 = torch.cuda.Stream(device=dev)
-            side2.wait_stream(torch.cuda.current_stream(dev))
-            rg = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side2):
-                with torch.cuda.graph(rg, stream=side2, capture_error_mode="thread_local"):
-                    rollout_steps(128)
-            torch.cuda.current_stream(dev).wait_stream(side2)
-            torch.cuda.synchronize()
-            rg.replay()
-            torch.cuda.synchronize()
-        except Exception:           # noqa: BLE001
-            rg = None
-        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        q0.record()
-        if rg is not None:
-            rg.replay()
-        else:
-            rollout_steps(128)
-        q1.record()
-        torch.cuda.synchronize()
-        rsec = q0.elapsed_time(q1) * 1e-3
+        rg, ra, rbv = (None, None, None) if args.no_graph else graph_of(rollout_steps, dev)
+        ms = timed_replay(rg, ra, rbv, rollout_steps, reps=2)
         result["rollout_random"] = {"metric": "board-steps/s, 1,048,576 boards x 128 consecutive in-place steps from reset, "
                                               "uniform actions drawn in the kernel, auto-reset (realistic tile distribution)",
-                                    "value": n * 128 / rsec, "unit": "board-steps/s", "us_per_step": rsec / 128 * 1e6}
+                                    "value": n * 128 / (ms * 1e-3), "unit": "board-steps/s", "us_per_step": ms * 1e3 / 128}
 
     # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
     if not args.no_rollout and world == 1:
@@ -326,33 +443,49 @@ def main():
         rres = {}
         for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("uniform_policy_env_only", Uniform())):
             rc = RolloutCollector(65536, 128, pol, device=dev, seed=SEED)
+            rc.collect()                    # includes the one-time graph capture
             rc.collect()
             torch.cuda.synchronize()
-            r0 = time.perf_counter()
-            rc.collect()
-            torch.cuda.synchronize()
-            rres[name] = 65536 * 128 / (time.perf_counter() - r0)
-        result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps (obs -> mask -> policy -> sample -> step, auto-reset)",
+            best = None
+            for _ in range(3 if name != "transformer_policy" else 1):
+                r0 = time.perf_counter()
+                rc.collect()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - r0
+                best = dt if best is None else min(best, dt)
+            rres[name] = 65536 * 128 / best
+            rres[name + "_graph"] = rc._graph is not None
+        result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps: policy -> g2048_rollout_step (sample + step + next "
+                                       "obs + next mask in one launch, auto-reset), the T-step loop replayed from one hipGraph",
                              "unit": "env-steps/s", **rres}
 
     # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the
-        # box's CPU share (16 for one GPU) or to the cores this process may run on, whichever is smaller
-        O.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        info = cpu_info()
         hb, ha = boards.cpu().numpy(), actions.cpu().numpy()
         hs = np.zeros(n, np.uint32)
         O.step_batch(hb[:4096], ha[:4096], hs[:4096], seed=SEED, step_index=0)       # load + warm
-        c0 = time.perf_counter(); passes = 0
-        while time.perf_counter() - c0 < args.cpu_seconds and passes < 1000:
-            bo, so, ro, fo = O.step_batch(hb, ha, hs, seed=SEED, step_index=W + passes, id_base=id_base)
-            passes += 1
-        csec = time.perf_counter() - c0
+
+        def time_steps(threads, seconds):
+            O.set_num_threads(threads)
+            c0 = time.perf_counter(); passes = 0; last = None
+            while time.perf_counter() - c0 < seconds and passes < 1000:
+                last = O.step_batch(hb, ha, hs, seed=SEED, step_index=W + passes, id_base=id_base)
+                passes += 1
+            return passes, time.perf_counter() - c0, last
+        # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the box's CPU
+        # share (16 for one GPU) or to the cores this process may run on, whichever is smaller
+        many = min(16, info["affinity"])
+        p1, s1, _ = time_steps(1, args.cpu_seconds * 0.4)
+        passes, csec, (bo_, so_, ro_, fo_) = time_steps(many, args.cpu_seconds * 0.6)
         result["cpu_baseline"] = {"value": n * passes / csec, "unit": "board-steps/s", "cores": O.num_threads(),
                                   "kind": "port",
                                   "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
-                                            "(%.1f s, OpenMP static over boards)" % (passes, csec)}
+                                            "(%.1f s, OpenMP static over boards)" % (passes, csec),
+                                  "one_thread": {"value": n * p1 / s1, "cores": 1,
+                                                 "sample": "%d passes, %.1f s" % (p1, s1)},
+                                  **info}
         from oracle import pyref
         prate = pyref.time_steps(4000, SEED)
         result["cpu_baseline_python"] = {"value": prate, "unit": "board-steps/s", "cores": 1, "kind": "port",
@@ -363,18 +496,27 @@ def main():
         # the last CPU pass doubles as a full-size parity check of what the GPU just computed
         one_step(W + passes - 1)
         torch.cuda.synchronize()
-        assert np.array_equal(out.cpu().numpy(), bo) and np.array_equal(flags.cpu().numpy(), fo), "GPU != oracle"
+        assert np.array_equal(out.cpu().numpy(), bo_) and np.array_equal(flags.cpu().numpy(), fo_), "GPU != oracle"
         if not args.no_beam:
             hr = roots.cpu().numpy()
-            c0 = time.perf_counter(); cexp = 0; cdec = 0
-            while time.perf_counter() - c0 < args.cpu_seconds and cdec < 100:
-                oa, op, oe = O.beam_batch(hr, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec, game_id_base=0)
-                cexp += int(oe.sum()); cdec += 1
-            csec = time.perf_counter() - c0
+
+            def time_beam(threads, seconds, cap):
+                O.set_num_threads(threads)
+                c0 = time.perf_counter(); cexp = 0; cdec = 0; last = None
+                while time.perf_counter() - c0 < seconds and cdec < cap:
+                    last = O.beam_batch(hr if threads > 1 else hr[:256], BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec,
+                                        game_id_base=0)
+                    cexp += int(last[2].sum()); cdec += 1
+                return cexp, cdec, time.perf_counter() - c0, last
+            e1, d1, sec1, _ = time_beam(1, args.cpu_seconds * 0.3, 100)
+            cexp, cdec, csec, (oa, op, oe) = time_beam(many, args.cpu_seconds * 0.6, 100)
             result["beam"]["cpu_baseline"] = {"value": cexp / csec, "unit": "expansions/s",
                                               "cores": O.num_threads(), "kind": "port",
                                               "sample": "%d batch decisions over the same 4096 roots (%.1f s, OpenMP "
-                                                        "dynamic over games)" % (cdec, csec)}
+                                                        "dynamic over games)" % (cdec, csec),
+                                              "one_thread": {"value": e1 / sec1, "cores": 1,
+                                                             "sample": "%d batch decisions over the first 256 roots, %.1f s" % (d1, sec1)},
+                                              **info}
             a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
                                           game_id_base=0, want_expanded=True)
             assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(e.cpu().numpy().astype(np.uint32), oe), \
@@ -385,6 +527,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

@@ -77,7 +77,11 @@ enum {
 /* opts of g2048_beam_get_action */
 #define G2048_BEAM_FIXED_DOWN  0x01u   /* use the true DOWN move instead of the reference's rot180 quirk (not parity) */
 
-#define G2048_BEAM_MAX_WIDTH   32
+#define G2048_BEAM_ONE_WAVE_PER_GAME 0x02u /* tuning / A-B only (results identical): widths 17..20 normally run four games per
+                                            256-thread block with the leftover children of all four handled by one wavefront;
+                                            this forces the one-wavefront-per-game kernel every other width uses */
+
+#define G2048_BEAM_MAX_WIDTH   128
 
 const char *g2048_last_error(void);
 int g2048_abi_version(void);
@@ -199,6 +203,64 @@ int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_n
                              int32_t *moves_inout, int32_t *valid_inout, int32_t *invalid_inout,
                              int32_t *milestone_move_inout, unsigned long long *expanded_sum_inout_or_null,
                              const uint32_t *keyblock, size_t n, void *stream);
+
+/* ---- PPO rollout step ---------------------------------------------------------------------------------------
+ * One step of a PPO rollout for n envs in ONE launch -- what PPOAgent.get_action's sampling (agents/ppo_agent.py:211-221),
+ * Game2048Env.step (environment/game_2048.py:170-210) and the preparation of the next policy call do between two forward
+ * passes of the policy: the action is drawn from `probs` (float32 [n][4]) under the valid-move mask exactly as
+ * g2048_sample_actions does (draw (seed, POLICY, index, env id)), the env is stepped exactly as g2048_step does (draw
+ * (seed, STEP, index, env id); auto-reset in the EPISODE domain), and from the board still in registers the kernel
+ * writes the NEXT observation (PPOAgent.normalize_state, :184-195; dtype by the OBS bits of opts) and the NEXT env
+ * valid-move mask (game_2048.py:69-95). mask4_in_or_null = NULL: the mask of the current board is computed in place.
+ * index = step_index + (step_counter_or_null ? *step_counter_or_null : 0): with a device counter the launch carries no
+ * host-side step number, so a hipGraph of a whole T-step rollout (step_index = 0..T-1 baked in, counter += T per replay)
+ * can be replayed. Optional outputs for the reward shaping below: next_boards_out (the next state BEFORE any auto-reset)
+ * and state_maxcode_out (max log2 code of the state the action was taken in). */
+#define G2048_ROLLOUT_OBS_SHIFT 4       /* opts bits 4..5: dtype of obs_next_out */
+#define G2048_OBS_F32  0u
+#define G2048_OBS_F16  1u
+#define G2048_OBS_BF16 2u
+int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t *mask4_in_or_null, void *boards_out,
+                       uint32_t *score_inout, uint8_t *actions_out, float *prob_out, void *reward_out, uint8_t *flags_out,
+                       void *obs_next_out_or_null, uint8_t *mask4_next_out_or_null, void *next_boards_out_or_null,
+                       uint8_t *state_maxcode_out_or_null, uint64_t seed, uint64_t step_index,
+                       const unsigned long long *step_counter_or_null, uint64_t env_id_base, size_t n, uint32_t opts,
+                       void *stream);
+
+/* ---- PPOAgent.remember reward shaping (agents/ppo_agent.py:234-269) for an ORDERED batch of n transitions ------------
+ * The reference calls remember() once per transition, and two of its terms carry state from call to call: the
+ * "new highest tile" bonus (:241-246, self.highest_tile_seen) and the novelty bonus (:259-262, self.seen_states).
+ * Batched with exactly the sequential semantics for the order i = 0..n-1 (a rollout buffer [T][N] flattened: step t,
+ * then env id), continued across calls through highest_code_inout / the table / index_base:
+ *   g2048_shaping_scan    prev_highest_out[i] = max(*highest_code_inout, max log2 code after transitions 0..i-1) -- the
+ *                         value highest_tile_seen has when the reference reaches transition i -- and then
+ *                         *highest_code_inout = the maximum over everything (device uint32; a fresh agent starts at 1
+ *                         = tile 2, ppo_agent.py:171). flags = the flags byte g2048_step / g2048_rollout_step wrote
+ *                         (bits 3..7 = max code of the next state). workspace: g2048_shaping_scan_workspace(n) bytes.
+ *   g2048_seen_insert     every next state is looked up / inserted in an open-addressing hash set keyed by the whole
+ *                         16-byte board (table: 2^capacity_log2 slots of G2048_SEEN_SLOT_BYTES bytes, zero-initialised by
+ *                         the caller; keep it at most half full); each key keeps the smallest transition index
+ *                         index_base + i that presented it. slot_out[i] = the key's slot. *count_inout grows by the
+ *                         number of new keys; *overflow_flag becomes non-zero if the table filled up.
+ *   g2048_shaping_apply   shaped_out[i] = the reward remember() stores: env_reward[i] (+ 5.0 * (log2 next_max - log2
+ *                         highest so far) if a new highest tile) (+ -2.0 * (log2 current_max - log2 next_max) if the
+ *                         max tile fell) + 0.1 * sum(log2 of the 4 largest tiles) (+ 0.2 if transition i is the FIRST
+ *                         in order to present its next state) + 0.3 * evaluate_heuristic(next_state), added in that
+ *                         order in f64. Call after g2048_seen_insert of the same batch (stream order is enough).
+ *   g2048_seen_rehash     re-inserts every key of a table into a larger zeroed one (first indices kept).
+ * The only deviation from the reference: its set holds Python hash() values of the board bytes, so two different boards
+ * whose 64-bit hashes collide count as one there; here keys are compared in full. */
+#define G2048_SEEN_SLOT_BYTES 32
+size_t g2048_shaping_scan_workspace(size_t n);
+int g2048_shaping_scan(const uint8_t *flags, uint8_t *prev_highest_out, uint32_t *highest_code_inout, void *workspace,
+                       size_t n, void *stream);
+int g2048_seen_insert(const void *next_boards, uint64_t index_base, void *table, uint32_t capacity_log2,
+                      unsigned long long *count_inout, uint32_t *overflow_flag, uint32_t *slot_out, size_t n, void *stream);
+int g2048_seen_rehash(const void *old_table, uint32_t old_capacity_log2, void *new_table, uint32_t new_capacity_log2,
+                      uint32_t *overflow_flag, void *stream);
+int g2048_shaping_apply(const void *next_boards, const uint8_t *state_maxcode, const uint8_t *flags, const double *env_reward,
+                        const uint8_t *prev_highest, const void *table, const uint32_t *slots, uint64_t index_base,
+                        double *shaped_out, uint8_t *novel_out_or_null, size_t n, void *stream);
 
 /* device self-test of the instruction-level assumptions the kernels rely on (v_perm_b32 byte order,
  * udot4, f64 contraction off). Writes 0 to *result_out (device uint32) when all hold. */

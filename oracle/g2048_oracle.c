@@ -10,6 +10,7 @@
  */
 #include "g2048_oracle.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -610,6 +611,120 @@ double g2048o_ppo_shaping(const int32_t b[16], double reward_in)
     reward += 0.1 * sum;
     reward += 0.3 * g2048o_ppo_heuristic(b);
     return reward;
+}
+
+/* PPOAgent.remember (agents/ppo_agent.py:234-269), the whole method with its agent-level state: highest_tile_seen (:171,
+ * starts at tile 2) and seen_states (:175; here a set of the boards themselves -- the reference stores Python's hash() of
+ * the board bytes, see DESIGN.md for that one deviation). Sequential by construction: call i sees the state calls 0..i-1
+ * left behind. */
+struct g2048o_remember_state {
+    int32_t highest_tile_seen;
+    size_t cap, count;              /* open addressing over whole boards; cap is a power of two */
+    int32_t *keys;                  /* cap x 16 */
+    uint8_t *used;
+};
+
+g2048o_remember_state *g2048o_remember_new(void)
+{
+    g2048o_remember_state *st = (g2048o_remember_state *)calloc(1, sizeof *st);
+    st->highest_tile_seen = 2;
+    st->cap = 1024;
+    st->keys = (int32_t *)calloc(st->cap * 16, sizeof(int32_t));
+    st->used = (uint8_t *)calloc(st->cap, 1);
+    return st;
+}
+
+void g2048o_remember_free(g2048o_remember_state *st)
+{
+    if (!st) return;
+    free(st->keys); free(st->used); free(st);
+}
+
+int32_t g2048o_remember_highest(const g2048o_remember_state *st) { return st->highest_tile_seen; }
+size_t g2048o_remember_seen(const g2048o_remember_state *st) { return st->count; }
+
+static size_t remember_hash(const int32_t b[16])
+{
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 16; ++i) { h ^= (uint64_t)(uint32_t)b[i]; h *= 1099511628211ull; }
+    return (size_t)(h ^ (h >> 29));
+}
+
+/* returns 1 if the board was not in the set (and adds it) */
+static int remember_add(g2048o_remember_state *st, const int32_t b[16])
+{
+    if (2 * (st->count + 1) > st->cap) {
+        const size_t ncap = st->cap * 2;
+        int32_t *nk = (int32_t *)calloc(ncap * 16, sizeof(int32_t));
+        uint8_t *nu = (uint8_t *)calloc(ncap, 1);
+        for (size_t i = 0; i < st->cap; ++i) {
+            if (!st->used[i]) continue;
+            size_t p = remember_hash(st->keys + 16 * i) & (ncap - 1);
+            while (nu[p]) p = (p + 1) & (ncap - 1);
+            memcpy(nk + 16 * p, st->keys + 16 * i, 16 * sizeof(int32_t)); nu[p] = 1;
+        }
+        free(st->keys); free(st->used);
+        st->keys = nk; st->used = nu; st->cap = ncap;
+    }
+    size_t p = remember_hash(b) & (st->cap - 1);
+    while (st->used[p]) {
+        if (memcmp(st->keys + 16 * p, b, 16 * sizeof(int32_t)) == 0) return 0;
+        p = (p + 1) & (st->cap - 1);
+    }
+    memcpy(st->keys + 16 * p, b, 16 * sizeof(int32_t)); st->used[p] = 1; st->count++;
+    return 1;
+}
+
+static int32_t board_max(const int32_t b[16])
+{
+    int32_t m = b[0];
+    for (int i = 1; i < 16; ++i) if (b[i] > m) m = b[i];
+    return m;
+}
+
+double g2048o_remember(g2048o_remember_state *st, const int32_t state[16], const int32_t next_state[16], double reward,
+                       int *novel_out)
+{
+    const int32_t current_max_tile = board_max(state), next_max_tile = board_max(next_state);       /* :237-238 */
+    if (next_max_tile > st->highest_tile_seen) {                                                    /* :241-246 */
+        const double tile_bonus = 5.0 * (log2((double)next_max_tile) - log2((double)st->highest_tile_seen));
+        st->highest_tile_seen = next_max_tile;
+        reward += tile_bonus;
+    }
+    if (next_max_tile < current_max_tile) {                                                         /* :249-251 */
+        const double regression_penalty = -2.0 * (log2((double)current_max_tile) - log2((double)next_max_tile));
+        reward += regression_penalty;
+    }
+    {                                                                                               /* :254-256 */
+        int32_t s[16]; memcpy(s, next_state, sizeof s);
+        for (int i = 1; i < 16; ++i) {
+            int32_t t = s[i]; int j = i - 1;
+            while (j >= 0 && s[j] > t) { s[j + 1] = s[j]; --j; }
+            s[j + 1] = t;
+        }
+        double sum = 0.0;
+        for (int i = 12; i < 16; ++i) if (s[i] > 0) sum += log2((double)s[i]);
+        reward += 0.1 * sum;
+    }
+    const int novel = remember_add(st, next_state);                                                 /* :259-262 */
+    if (novel) reward += 0.2;
+    if (novel_out) *novel_out = novel;
+    reward += 0.3 * g2048o_ppo_heuristic(next_state);                                               /* :265-266 */
+    return reward;
+}
+
+/* n transitions in order over the packed layout */
+void g2048o_remember_batch(g2048o_remember_state *st, const uint8_t *state_codes, const uint8_t *next_codes,
+                           const double *reward_in, double *reward_out, uint8_t *novel_out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        int32_t a[16], b[16];
+        g2048o_unpack(state_codes + 16 * i, a, 1);
+        g2048o_unpack(next_codes + 16 * i, b, 1);
+        int nv;
+        reward_out[i] = g2048o_remember(st, a, b, reward_in[i], &nv);
+        if (novel_out) novel_out[i] = (uint8_t)nv;
+    }
 }
 
 /* Masked sampling of PPOAgent.get_action (agents/ppo_agent.py:211-221): weights p_a + 1e-10 on the valid actions

@@ -77,6 +77,18 @@ double g2048o_monotonicity(const int32_t b[16], int row_dir, int col_dir);      
 double g2048o_ppo_heuristic(const int32_t b[16]);                                /* :271-298 */
 double g2048o_ppo_shaping(const int32_t b[16], double reward_in);                /* :253-266, pure terms */
 
+/* PPOAgent.remember (:234-269) complete, with the agent's running state (highest_tile_seen :171, seen_states :175);
+ * returns the reward remember() stores; sequential -- call order is the semantics */
+typedef struct g2048o_remember_state g2048o_remember_state;
+g2048o_remember_state *g2048o_remember_new(void);
+void    g2048o_remember_free(g2048o_remember_state *st);
+int32_t g2048o_remember_highest(const g2048o_remember_state *st);
+size_t  g2048o_remember_seen(const g2048o_remember_state *st);
+double  g2048o_remember(g2048o_remember_state *st, const int32_t state[16], const int32_t next_state[16], double reward,
+                        int *novel_out);
+void    g2048o_remember_batch(g2048o_remember_state *st, const uint8_t *state_codes, const uint8_t *next_codes,
+                              const double *reward_in, double *reward_out, uint8_t *novel_out, size_t n);
+
 /* ---- batched forms over the packed layout (full-size checks, cpu_baseline) ---- */
 void g2048o_synth_boards(uint8_t *codes, uint64_t seed, uint64_t id_base, size_t n,
                          uint32_t p_empty_u16, uint32_t max_code);

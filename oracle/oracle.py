@@ -80,6 +80,12 @@ def lib():
                                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]),
             "g2048o_sample_action": (C.c_int, [f32p, C.c_int, C.c_uint32, f32p]),
             "g2048o_sample_batch": (None, [f32p, u8p, u8p, f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
+            "g2048o_remember_new": (C.c_void_p, []),
+            "g2048o_remember_free": (None, [C.c_void_p]),
+            "g2048o_remember_highest": (C.c_int32, [C.c_void_p]),
+            "g2048o_remember_seen": (C.c_size_t, [C.c_void_p]),
+            "g2048o_remember": (C.c_double, [C.c_void_p, i32p, i32p, C.c_double, C.POINTER(C.c_int)]),
+            "g2048o_remember_batch": (None, [C.c_void_p, u8p, u8p, f64p, f64p, u8p, C.c_size_t]),
             "g2048o_num_threads": (C.c_int, []),
             "g2048o_set_num_threads": (None, [C.c_int]),
         }
@@ -313,3 +319,42 @@ def num_threads():
 
 def set_num_threads(n):
     lib().g2048o_set_num_threads(int(n))
+
+
+# ------------------------------------------------------- PPOAgent.remember ---
+class Remember:
+    """PPOAgent.remember (agents/ppo_agent.py:234-269) with the agent's running state; strictly sequential."""
+
+    def __init__(self):
+        self._st = lib().g2048o_remember_new()
+
+    def __del__(self):
+        try:
+            lib().g2048o_remember_free(self._st)
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    @property
+    def highest_tile_seen(self):
+        return lib().g2048o_remember_highest(self._st)
+
+    @property
+    def n_seen(self):
+        return lib().g2048o_remember_seen(self._st)
+
+    def one(self, state, next_state, reward):
+        nv = C.c_int()
+        r = lib().g2048o_remember(self._st, _p(_i32(state), C.c_int32), _p(_i32(next_state), C.c_int32), float(reward),
+                                  C.byref(nv))
+        return r, bool(nv.value)
+
+    def batch(self, state_codes, next_codes, reward_in):
+        """uint8 (n,16) log2 codes, f64 (n,) -> (reward_out f64 (n,), novel bool (n,)), in order."""
+        a = np.ascontiguousarray(state_codes, dtype=np.uint8).reshape(-1, 16)
+        b = np.ascontiguousarray(next_codes, dtype=np.uint8).reshape(-1, 16)
+        r = np.ascontiguousarray(reward_in, dtype=np.float64)
+        out = np.empty(a.shape[0], dtype=np.float64)
+        nov = np.empty(a.shape[0], dtype=np.uint8)
+        lib().g2048o_remember_batch(self._st, _p(a, C.c_uint8), _p(b, C.c_uint8), _p(r, C.c_double), _p(out, C.c_double),
+                                    _p(nov, C.c_uint8), a.shape[0])
+        return out, nov.astype(bool)

@@ -520,7 +520,75 @@ def gen_rng_pin():
     print("rng_pin", a.shape[0])
 
 
+def gen_remember():
+    """PPOAgent.remember (agents/ppo_agent.py:234-269) run SEQUENTIALLY by the reference over an ordered list of
+    transitions, all of its terms live (highest_tile_seen and seen_states start fresh, as a new agent's do):
+      part 1  a vectorised rollout in (step, env) order: 24 reference envs x 150 steps, auto-reset when an episode ends; envs
+              2k and 2k+1 are twins (same draws, same actions) for their first 6 steps, so the novelty term sees repeats;
+      part 2  320 transitions between unrelated boards (max tile falling, rising by several doublings, huge tiles),
+              which exercises the regression term the reference's own episode loop never reaches.
+    Stored: state / next_state codes, the reward passed in, the reward remember() stored, and the agent's final state."""
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        from agents.ppo_agent import PPOAgent
+        ppo = PPOAgent()
+    assert ppo.highest_tile_seen == 2 and len(ppo.seen_states) == 0
+    n_env, n_steps, twin_steps = 24, 150, 6
+    envs = [Game2048Env() for _ in range(n_env)]
+
+    def gid_at(e, t):           # twins share a draw / action identity for the first steps
+        return 9000 + (e - (e & 1) if t < twin_steps else e)
+
+    states = []
+    for e, env in enumerate(envs):
+        g = gid_at(e, 0)
+        STREAM.source = list_source([hashed(O.DOM_RESET, 0, g, 0), hashed(O.DOM_RESET, 0, g, 1)])
+        states.append(env.reset())
+    S, NS, RIN, ROUT, DONE = [], [], [], [], []
+
+    def feed(state, next_state, reward, done):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ppo.remember(state.copy(), 0, 0.0, reward, next_state.copy(), done)
+        S.append(codes_of(state)); NS.append(codes_of(next_state)); RIN.append(float(reward))
+        ROUT.append(float(ppo.memory.buffer[-1][3])); DONE.append(bool(done))
+        ppo.memory.buffer.clear()
+
+    for t in range(n_steps):
+        for e, env in enumerate(envs):
+            g = gid_at(e, t)
+            a = int(hashed(O.DOM_SYNTH_ACTION, t, g) >> 30)
+            STREAM.source = list_source([hashed(O.DOM_STEP, t, g)])
+            ns, r, d, info = env.step(a)
+            feed(states[e], ns, r, d)
+            if d:
+                STREAM.source = list_source([hashed(O.DOM_EPISODE, t, g, 0), hashed(O.DOM_EPISODE, t, g, 1)])
+                ns = env.reset()
+            states[e] = ns
+    n_rollout = len(S)
+    rng = np.random.default_rng(4242)
+    pool = np.concatenate([random_code_boards(rng, 200, 0.3, 11), random_code_boards(rng, 60, 0.5, 17),
+                           random_code_boards(rng, 60, 0.0, 4)]).astype(np.uint8)
+    pool[pool.max(axis=1) == 0, 0] = 1
+    for i in range(320):
+        a, b = pool[rng.integers(pool.shape[0])], pool[rng.integers(pool.shape[0])]
+        if i % 5 == 0:
+            b = a                      # an exact repeat of an earlier / the same board
+        feed(tiles_of(a), tiles_of(b), float(rng.normal() * 3.0), False)
+    rout, rin = np.array(ROUT), np.array(RIN)
+    print("remember", len(S), "transitions; novel", int(len(ppo.seen_states)), "highest", int(ppo.highest_tile_seen),
+          "dones", int(np.sum(DONE)))
+    np.savez_compressed(os.path.join(HERE, "remember.npz"), state=np.array(S, np.uint8), next_state=np.array(NS, np.uint8),
+                        reward_in=rin, reward_out=rout, done=np.array(DONE, np.uint8), n_rollout=np.int64(n_rollout),
+                        n_env=np.int64(n_env), final_highest_tile=np.int64(ppo.highest_tile_seen),
+                        final_seen=np.int64(len(ppo.seen_states)))
+
+
 def main():
+    if "--only" in sys.argv:
+        what = sys.argv[sys.argv.index("--only") + 1]
+        {"remember": gen_remember}[what]()
+        return
     O.build()
     rng = np.random.default_rng(2048)
     t0 = time.time()
@@ -575,6 +643,7 @@ def main():
     gen_beam_masks(np.concatenate([edges, random_code_boards(np.random.default_rng(321), 60, 0.05, 4),
                                    random_code_boards(np.random.default_rng(322), 25, 0.4, 8)]).astype(np.uint8))
     gen_episodes()
+    gen_remember()
     print("done in %.1fs" % (time.time() - t0))
 
 

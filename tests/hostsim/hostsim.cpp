@@ -14,6 +14,13 @@
 
 using namespace g2048;
 
+static const uint32_t kDirTable[G2048_DIR_TABLE_WORDS] = G2048_DIR_TABLE_INIT;
+static DirSel dir_sel(uint32_t action)
+{
+    const uint32_t *t = kDirTable + 8 * (action & 3u);
+    return DirSel{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]};
+}
+
 static Board ld(const uint8_t *p) { Board b; memcpy(b.w, p, 16); return b; }
 static void st(uint8_t *p, const Board &b) { memcpy(p, b.w, 16); }
 
@@ -32,7 +39,12 @@ void hs_move(const uint8_t *in, const uint8_t *actions, int agent, uint8_t *out,
     for (size_t i = 0; i < n; ++i) {
         const Board b = ld(in + 16 * i);
         uint32_t g;
-        const Board o = agent ? move_agent(b, actions[i] & 3u, g, false) : move_env(b, actions[i] & 3u, g);
+        Board o = agent ? move_agent(b, actions[i] & 3u, g, false) : move_env(b, actions[i] & 3u, g);
+        if (!agent) {       // the table-driven direction network must agree with the select-based move on everything
+            uint32_t g2, m1, m2;
+            const Board o1 = move_env(b, actions[i] & 3u, g, m1), o2 = move_env_sel(b, dir_sel(actions[i]), g2, m2);
+            if (!same(o1, o2) || g2 != g || m1 != m2) o.w[0] = 0xffffffffu;
+        }
         st(out + 16 * i, o); gain[i] = g; valid[i] = !same(o, b);
     }
 }
@@ -58,7 +70,12 @@ void hs_step(const uint8_t *in, const uint8_t *actions, const uint32_t *h, uint8
              double *reward, uint8_t *flags, size_t n)
 {
     for (size_t i = 0; i < n; ++i) {
-        const StepOut o = step_board(ld(in + 16 * i), actions[i] & 3u, h[i]);
+        const StepOut o = step_board_sel(ld(in + 16 * i), dir_sel(actions[i]), h[i]);      // what step_kernel runs
+        const StepOut o2 = step_board(ld(in + 16 * i), actions[i] & 3u, h[i]);             // what play_kernel runs
+        if (!same(o.board, o2.board) || o.gain != o2.gain || o.flags != o2.flags || memcmp(&o.reward, &o2.reward, 8) != 0) {
+            st(out + 16 * i, Board{{0xffffffffu, 0, 0, 0}});
+            continue;
+        }
         st(out + 16 * i, o.board); score[i] += o.gain; reward[i] = o.reward; flags[i] = (uint8_t)o.flags;
     }
 }

@@ -49,7 +49,7 @@ def test_argument_validation_without_device(built):
     assert b"aligned" in L.g2048_last_error()
     assert L.g2048_eval(None, 0, None, None, 0, None) == 0          # n == 0 is a no-op
     al = base + (16 - base % 16) % 16
-    assert L.g2048_beam_get_action(al, None, al, al, None, 64, 30, 512, 1024, 0, 0, 0, 1, 0, None) == -1
+    assert L.g2048_beam_get_action(al, None, al, al, None, 129, 30, 512, 1024, 0, 0, 0, 1, 0, None) == -1
     assert b"width" in L.g2048_last_error()
     assert L.g2048_valid_moves(al, al, 1, 7, None) == -1
     assert L.g2048_step(al, al, al, al, al, al, 0, 0, 0, 1, 0x80, None) == -1
@@ -66,7 +66,7 @@ def test_host_layer_fails_loudly_on_cpu(built):
     with pytest.raises(RuntimeError):
         VecGame2048(8, device="cpu")
     with pytest.raises(ValueError):
-        BatchedBeamSearch(beam_width=64)
+        BatchedBeamSearch(beam_width=129)
     if not torch.cuda.is_available():
         from environment.game_2048 import Game2048Env
         with pytest.raises(Exception):

@@ -136,3 +136,34 @@ def test_beam_fuzz(ops, oracle, width, depth, p_empty, max_code):
     oa, op, oe = oracle.beam_batch(hb, width, depth, seed=12, step_index=3, game_id_base=3 << 34)
     assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
     assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+
+
+@pytest.mark.parametrize("width,depth,n", [(33, 12, 512), (48, 20, 384), (64, 30, 256), (100, 8, 256), (128, 14, 192)])
+def test_beam_wide_beams_vs_oracle(ops, oracle, width, depth, n):
+    """The reference accepts any beam_width (agents/beam_search_agent.py:13-22): widths above 32 run stage A in rounds of
+    32 parents and stage B in up to eight 64-lane passes; actions, probabilities and expansion counts vs the oracle."""
+    hb = np.concatenate([oracle.synth_boards(n // 2, seed=width), oracle.synth_boards(n - n // 2, seed=width + 1, p_empty=0.05, max_code=5)])
+    a, p, e = ops.beam_get_action(dev(hb), width, depth, seed=7, step_index=width, game_id_base=77, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(hb, width, depth, seed=7, step_index=width, game_id_base=77)
+    assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+    assert int(oe.max()) > 64 * 4          # more than four passes' worth of children on some level sum
+
+
+@pytest.mark.parametrize("width", [17, 18, 19, 20])
+@pytest.mark.parametrize("n", [1, 3, 4, 4097])
+def test_beam_four_games_per_block_equals_one_wave_per_game(ops, oracle, width, n):
+    """Widths 17..20 run four games per block with shared leftover handling and a radix-select top-k; the
+    one-wavefront-per-game kernel (G2048_BEAM_ONE_WAVE_PER_GAME) and the oracle must agree with it on everything --
+    ragged game counts, dead roots, single-move roots, caller masks included."""
+    hb = np.concatenate([oracle.synth_boards(n - n // 3, seed=900 + width, p_empty=0.2, max_code=9),
+                         oracle.synth_boards(n // 3, seed=901 + width, p_empty=0.0, max_code=3)])
+    for mask in (None, dev(oracle.valid_moves_batch(hb, False))):
+        a, p, e = ops.beam_get_action(dev(hb), width, 30, mask, seed=21, step_index=5, game_id_base=(1 << 33) + 9, want_expanded=True)
+        b, q, f = ops.beam_get_action(dev(hb), width, 30, mask, seed=21, step_index=5, game_id_base=(1 << 33) + 9, want_expanded=True,
+                                      one_wave_per_game=True)
+        assert bool((a == b).all()) and bool((p == q).all()) and bool((e == f).all())
+        oa, op, oe = oracle.beam_batch(hb, width, 30, mask=None if mask is None else mask.cpu().numpy(), seed=21, step_index=5,
+                                       game_id_base=(1 << 33) + 9)
+        assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
+        assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)

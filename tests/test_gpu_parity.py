@@ -88,6 +88,20 @@ def test_step_vs_oracle_sizes(ops, oracle, n):
         assert set(np.unique(host(a))) == {0, 1, 2, 3}
 
 
+@pytest.mark.parametrize("tune", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 1023, 4097, 300001])
+def test_step_boards_per_lane_variants(ops, oracle, tune, n):
+    """The G2048_STEP_TUNE instantiations (1 / 2 / 4 boards per lane) are public opts: same results as the oracle,
+    also when n is not a multiple of the block tile."""
+    b = ops.synth_boards(n, seed=SEED + 9, device=DEV, p_empty=0.1, max_code=5)
+    a = ops.synth_actions(n, seed=SEED + 9, step_index=3, device=DEV)
+    sc = torch.full((n,), 7, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, seed=SEED, step_index=3, id_base=11, reward_f64=True, auto_reset=True, tune=tune)
+    bo, so, ro, fo = oracle.step_batch(host(b), host(a), np.full(n, 7, np.uint32), seed=SEED, step_index=3, id_base=11, opts=1)
+    assert np.array_equal(host(out), bo) and np.array_equal(host(sc).astype(np.uint32), so)
+    assert np.array_equal(host(rw), ro, equal_nan=True) and np.array_equal(host(fl), fo)
+
+
 def test_step_in_place_and_auto_reset(ops, oracle):
     n = 200000
     hb = oracle.synth_boards(n, seed=5, p_empty=0.02, max_code=3)       # dense: many boards die

@@ -62,18 +62,122 @@ def test_masked_sample_semantics(g2048):
     assert abs(float((a2 == 0).float().mean()) - 0.7) < 0.02
 
 
+def oracle_remember_of_rollout(oracle, R, res, rc, n, T, seed, id_base, b, sc, t0):
+    """remember() applied sequentially, in (step, env) order, to the transitions the collector recorded: the oracle replays
+    the env with the recorded actions -- once without auto-reset for the next state remember() sees, once with it for the
+    state the rollout continues from."""
+    acts = res["actions"].cpu().numpy()
+    shaped = np.empty((T, n), np.float64)
+    for t in range(T):
+        nb, _, r, fl = oracle.step_batch(b, acts[t], sc.copy(), seed=seed, step_index=t0 + t, id_base=id_base, opts=0)
+        shaped[t], _ = R.batch(b, nb, r)
+        b, sc, _, _ = oracle.step_batch(b, acts[t], sc, seed=seed, step_index=t0 + t, id_base=id_base, opts=1)
+    return shaped, b, sc
+
+
 def test_rollout_small_with_shaping(g2048, oracle):
+    """RolloutCollector(shaping=True): the env side against the oracle, and the shaped reward -- PPOAgent.remember with
+    its two stateful terms -- against the oracle's SEQUENTIAL remember over the same transitions, across two collects."""
     torch.manual_seed(1)
     n, T = 2048, 96
     pol = TinyTransformerPolicy().to(DEV).eval()
-    rc = g2048.RolloutCollector(n, T, pol, device=DEV, seed=11, id_base=5, shaping=True)
+    rc = g2048.RolloutCollector(n, T, pol, device=DEV, seed=11, id_base=5, shaping=True, seen_capacity_log2=8)
     res = rc.collect()
-    b = replay_and_check(oracle, res, n, T, 11, 5)
-    assert int(res["dones"].sum()) >= 0 and res["values"].abs().sum() > 0
-    # shaping term of the last step's next state
-    assert np.array_equal(res["shaping"][T - 1].cpu().numpy(), oracle.eval_batch(b, oracle.EVAL_PPO_SHAPING))
-    res2 = rc.collect()      # a second rollout continues the same episodes (step counter keeps running)
+    replay_and_check(oracle, res, n, T, 11, 5)
+    assert res["values"].abs().sum() > 0
+    R = oracle.Remember()
+    b, sc = oracle.reset_batch(n, seed=11, epoch=0, id_base=5)
+    want, b, sc = oracle_remember_of_rollout(oracle, R, res, rc, n, T, 11, 5, b, sc, 0)
+    assert np.array_equal(res["shaping"].cpu().numpy(), want)
+    res2 = rc.collect()      # a second rollout continues the same episodes, the same seen-set and highest tile
     assert rc.env.t == 2 * T and rc.env_steps == 2 * n * T
+    want2, b, sc = oracle_remember_of_rollout(oracle, R, res2, rc, n, T, 11, 5, b, sc, T)
+    assert np.array_equal(res2["shaping"].cpu().numpy(), want2)
+    assert len(rc.seen) == R.n_seen and (1 << int(rc.seen.highest.item())) == R.highest_tile_seen
+    assert rc.seen.capacity_log2 > 8          # the table grew by rehashing on the way
+
+
+def test_remember_shaping_golden(g2048, oracle):
+    """ops.remember_shaping against what the reference's own remember() stored (tests/golden/remember.npz), f64 ==, fed
+    in pieces through a table that starts tiny (2^4 slots) so that it is rehashed several times."""
+    from conftest import load_golden
+    from g2048 import ops
+    g = load_golden("remember.npz")
+    n = g["state"].shape[0]
+    nxt = torch.from_numpy(g["next_state"]).to(DEV)
+    state_max = torch.from_numpy(g["state"].max(axis=1).astype(np.uint8)).to(DEV)
+    flags = torch.from_numpy((g["next_state"].max(axis=1).astype(np.uint8) << 3)).to(DEV)
+    rin = torch.from_numpy(g["reward_in"]).to(DEV)
+    seen = ops.SeenStates(DEV, capacity_log2=4)
+    got, nov = [], []
+    for lo, hi in ((0, 5), (5, 1000), (1000, 1001), (1001, n)):
+        o, v = ops.remember_shaping(seen, nxt[lo:hi].contiguous(), state_max[lo:hi].contiguous(), flags[lo:hi].contiguous(),
+                                    rin[lo:hi].contiguous(), want_novel=True)
+        got.append(o.cpu().numpy()); nov.append(v.cpu().numpy())
+    assert np.array_equal(np.concatenate(got), g["reward_out"])
+    assert len(seen) == int(g["final_seen"]) == int(np.concatenate(nov).sum())
+    assert (1 << int(seen.highest.item())) == int(g["final_highest_tile"])
+    assert seen.index == n and int(seen.overflow.item()) == 0
+
+
+def test_remember_shaping_large_ordered_batch(g2048, oracle):
+    """1.2 M transitions with heavy repetition (65,536 distinct boards): first-occurrence-in-order and the running
+    maximum are exact for a batch far larger than a wave / a block / a scan tile."""
+    from g2048 import ops
+    n, distinct = 1_200_000, 65536
+    rng = np.random.default_rng(5)
+    pool = oracle.synth_boards(distinct, seed=77)
+    pool[:, 0] = np.maximum(pool[:, 0], 1)
+    pick = rng.integers(0, distinct, n)
+    nxt_h = pool[pick]
+    # codes ramp up slowly so that the running maximum changes at many places of the batch
+    cap = np.minimum(17, 1 + (np.arange(n) // 80000)).astype(np.uint8)
+    nxt_h = np.minimum(nxt_h, cap[:, None])
+    st_h = pool[rng.integers(0, distinct, n)]
+    rin_h = rng.normal(size=n)
+    R = oracle.Remember()
+    want, wnov = R.batch(st_h, nxt_h, rin_h)
+    seen = ops.SeenStates(DEV, capacity_log2=10)
+    got, nov = ops.remember_shaping(seen, torch.from_numpy(nxt_h).to(DEV), torch.from_numpy(st_h.max(axis=1)).to(DEV),
+                                    torch.from_numpy(nxt_h.max(axis=1) << 3).to(DEV), torch.from_numpy(rin_h).to(DEV),
+                                    want_novel=True)
+    assert np.array_equal(nov.cpu().numpy().astype(bool), wnov)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert len(seen) == R.n_seen
+
+
+def test_fused_rollout_step_equals_unfused_ops(g2048):
+    """g2048_rollout_step == g2048_sample_actions -> g2048_step -> g2048_obs_* -> g2048_valid_moves, bit for bit, for every
+    observation dtype, f32 / f64 reward, given / recomputed mask, host step index / device counter."""
+    from g2048 import ops
+    torch.manual_seed(9)
+    n, seed, idb = 70001, 0xFEED, 123456789
+    b = ops.synth_boards(n, seed=5, device=DEV, p_empty=0.2, max_code=6)
+    b[:500] = ops.synth_boards(500, seed=6, device=DEV, p_empty=0.0, max_code=3)          # many finished / nearly dead boards
+    probs = torch.softmax(torch.randn(n, 4, device=DEV) * 2, 1).contiguous()
+    m = ops.valid_moves(b)
+    counter = torch.tensor([40], dtype=torch.int64, device=DEV)
+    for odt, rdt, give_mask, use_counter in ((torch.float32, torch.float32, True, False), (torch.float16, torch.float64, False, True),
+                                             (torch.bfloat16, torch.float32, True, True)):
+        t = 47
+        sc1 = torch.arange(n, dtype=torch.int32, device=DEV); sc2 = sc1.clone()
+        a1, p1 = ops.sample_actions(probs, m, seed=seed, step_index=t, id_base=idb)
+        o1, r1, f1 = ops.step(b, a1, sc1, seed, t, idb, reward_f64=rdt == torch.float64, auto_reset=True)
+        obs1, m1 = ops.obs(o1, dtype=odt), ops.valid_moves(o1)
+        nb_ref, _, _ = ops.step(b, a1, sc1.clone(), seed, t, idb, auto_reset=False)
+        obs2 = torch.empty((n, 16), dtype=odt, device=DEV); m2 = torch.empty(n, dtype=torch.uint8, device=DEV)
+        nb2 = torch.empty_like(b); sm2 = torch.empty(n, dtype=torch.uint8, device=DEV)
+        o2, a2, p2, r2, f2 = ops.rollout_step(b, probs, sc2, seed, 7 if use_counter else t, idb, mask=m if give_mask else None,
+                                              reward=torch.empty(n, dtype=rdt, device=DEV), obs_next=obs2, mask_next=m2,
+                                              next_boards=nb2, state_maxcode=sm2, auto_reset=True,
+                                              step_counter=counter if use_counter else None)
+        assert bool((a1 == a2).all()) and bool((p1 == p2).all())
+        assert bool((o1 == o2).all()) and bool((f1 == f2).all()) and bool((sc1 == sc2).all())
+        assert np.array_equal(r1.cpu().numpy(), r2.cpu().numpy(), equal_nan=True)
+        assert bool((obs1.view(torch.int16 if odt != torch.float32 else torch.int32) ==
+                     obs2.view(torch.int16 if odt != torch.float32 else torch.int32)).all()) and bool((m1 == m2).all())
+        assert bool((nb2 == nb_ref).all()) and bool((sm2 == b.max(dim=1).values).all())
+        assert int((f1 & 1).sum()) > 0          # auto-resets happened
 
 
 def test_config4_rollout_65536x128(g2048, oracle):

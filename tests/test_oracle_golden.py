@@ -200,3 +200,22 @@ def test_beam_arbitrary_masks_and_random_fallback(oracle):
         assert (r["action"], r["prob"], r["consumed"]) == (g["action"][i], g["prob"][i], g["consumed"][i]), i
         fb += int(g["prob"][i] == 0.5 and g["mask"][i] != 0)
     assert fb >= 5
+
+
+def test_remember_sequential_golden(oracle):
+    """PPOAgent.remember (agents/ppo_agent.py:234-269) with every term live -- the oracle's sequential restatement against
+    what the reference stored for the same ordered transitions (tests/golden/gen_golden.py:gen_remember), f64 ==, also
+    when the sequence is fed in pieces (the agent's state carries over)."""
+    g = load_golden("remember.npz")
+    n = g["state"].shape[0]
+    R = oracle.Remember()
+    out, nov = R.batch(g["state"], g["next_state"], g["reward_in"])
+    assert np.array_equal(out, g["reward_out"])
+    assert R.highest_tile_seen == int(g["final_highest_tile"]) and R.n_seen == int(g["final_seen"]) == int(nov.sum())
+    R2 = oracle.Remember()
+    parts = []
+    for lo, hi in ((0, 7), (7, 1000), (1000, n)):
+        parts.append(R2.batch(g["state"][lo:hi], g["next_state"][lo:hi], g["reward_in"][lo:hi])[0])
+    assert np.array_equal(np.concatenate(parts), g["reward_out"])
+    # the two stateful terms really fire in the fixture
+    assert 0 < int(nov.sum()) < n and int(g["done"].sum()) > 0
