@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * kSharedGames) void beam_shared_kernel(
     const int my_levels = active ? max(actual_depth, 1) : 0;
 
     int nb = 0;
-    uint32_t draws = 0, expanded = 0;
+    uint32_t draws = 0, expanded = 0, hi = root_max;
     for (uint32_t level = 0; level < block_levels; ++level) {
         const bool fast = level == 0 || level > 3;             // :122, :139 (block-uniform)
         const bool run = active && (int)level < my_levels;     // wave-uniform
@@ -423,12 +423,18 @@ __global__ __launch_bounds__(64 * kSharedGames) void beam_shared_kernel(
             const uint32_t key2 = lane < (uint32_t)kSharedLeft ? G.lkey[lane] : 0u;
             uint32_t rank1 = 0xffffu, rank2 = 0xffffu;
             if (fast) {
-                // radix select of the k largest keys over the two slots; keys are unique and < 2^27
+                // radix select of the k largest keys over the two slots, from the highest bit any key can have set: keys
+                // are unique, key = score * 256 + (255 - index) with score < 2 * 2^cc + 512 <= 2^(max(cc, 7) + 2), cc = the
+                // largest corner code <= hi = the largest code on any board of this level (tracked: a move raises a
+                // board's maximum by at most one)
+                const uint32_t lmax2 = live2 ? G.lmax[lane] : 0u;
+                if (__ballot(c1.cmax > hi || lmax2 > hi)) hi += 1u;               // wave-uniform
+                const int top = (int)min(30u, max(hi, 7u) + 9u);
                 unsigned long long A1 = __ballot(live1), A2 = __ballot(live2), S1 = 0ull, S2 = 0ull;
                 uint32_t k = min((uint32_t)width, total_valid);
                 if (total_valid <= (uint32_t)width) { S1 = A1; S2 = A2; k = 0u; }
-                uint32_t s1 = c1.key << 5, s2 = key2 << 5;                       // bit 26 -> bit 31
-                for (int bit = 26; bit >= 0 && k != 0u; --bit) {
+                uint32_t s1 = c1.key << (31 - top), s2 = key2 << (31 - top);      // bit `top` -> bit 31
+                for (int bit = top; bit >= 0 && k != 0u; --bit) {
                     const unsigned long long M1 = __ballot((int32_t)s1 < 0) & A1, M2 = __ballot((int32_t)s2 < 0) & A2;
                     s1 += s1; s2 += s2;
                     const uint32_t c = popc64(M1) + popc64(M2);
@@ -453,6 +459,8 @@ __global__ __launch_bounds__(64 * kSharedGames) void beam_shared_kernel(
                 if (sel1) rank1 = r1;
                 if (sel2) rank2 = r2;
             } else {
+                const uint32_t lmax2 = live2 ? G.lmax[lane] : 0u;
+                if (__ballot(c1.cmax > hi || lmax2 > hi)) hi += 1u;
                 const double sc2 = live2 ? G.score[64u + lane] : -INFINITY;
                 uint32_t r1 = 0u, r2 = 0u;
                 const uint32_t ci2 = 64u + lane;

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint8_t *_
 
 // ---------------------------------------------------------------- seen-states set ----
 // Slot = 32 bytes: key (the 16-byte board), first = smallest global transition index that presented the key, state
-// (0 empty, 1 being written, 2 full). Every access to table memory that can race inside a launch is an agent-scope
-// atomic (key halves are written once, by the lane that won the 0 -> 1 exchange, and drained before state becomes 2).
+// (0 empty, 1 being written, 2 full). Key halves are written once, by the lane that won the 0 -> 1 exchange, and are
+// performed before state becomes 2.
 struct SeenSlot { unsigned long long key_lo, key_hi, first; uint32_t state, pad; };
 static_assert(sizeof(SeenSlot) == G2048_SEEN_SLOT_BYTES, "slot layout is part of the ABI");
 
@@ -273,27 +273,29 @@ __device__ __forceinline__ uint32_t seen_upsert(SeenSlot *table, uint32_t mask, 
     const unsigned long long khi = (unsigned long long)key.z | ((unsigned long long)key.w << 32);
     uint32_t slot = board_hash(key) & mask, result = 0xffffffffu;
     inserted = false;
-    // Every lane leaves the loop through its HEAD (the `done` flag), never from inside the body: a lane that has won a
-    // slot must execute its stores inside the iteration it won in, because other lanes of the same wave may be waiting
-    // for exactly that slot to open, and code placed on a loop-exit path only runs once the whole wave has left the loop.
-    // `spins` bounds the wait on a slot another lane is still writing, so that no input can hang the launch.
+    // The loop condition is WAVE-UNIFORM (a ballot): a lane that has won a slot must execute its stores inside the
+    // iteration it won in, because other lanes of the same wave may be waiting for exactly that slot to open. With a
+    // per-lane exit the compiler is free to treat "store, then leave" as a loop-exit path, which only runs once the whole
+    // wave has left the loop -- the waiting lanes then never see the slot open (observed: rehash lost 3 % of its keys to
+    // the spin bound). `spins` bounds the wait on a slot another lane is still writing, so that no input can hang a launch.
+    // Inside a launch every access to the table is a returning read-modify-write atomic: those execute at the device's
+    // coherence point. (Loads, agent-scope sc1 loads included, are L2-served, and the eight XCDs' L2s are not coherent with
+    // each other; rather than depend on which hand-off forms happen to be safe, no load is used here. Not a hot path.)
     bool done = false;
-    for (uint32_t probes = 0, spins = 0; !done; ) {
+    uint32_t probes = 0, spins = 0;
+    while (__ballot(!done) != 0ull) {               // wave-uniform: nobody leaves before everybody is done (see above)
+        if (done) continue;
         SeenSlot *s = table + slot;
-        uint32_t st = __hip_atomic_load(&s->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == 0u) st = atomicCAS(&s->state, 0u, 1u);          // st == 0 afterwards: this lane owns the slot
+        const uint32_t st = atomicCAS(&s->state, 0u, 1u);         // 0: this lane owns the slot now
         if (st == 0u) {
-            __hip_atomic_store(&s->key_lo, klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&s->key_hi, khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&s->first, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the three stores have left before the slot opens
-            __hip_atomic_store(&s->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long o0 = atomicExch(&s->key_lo, klo), o1 = atomicExch(&s->key_hi, khi), o2 = atomicExch(&s->first, idx);
+            asm volatile("s_waitcnt vmcnt(0)" :: "v"(o0), "v"(o1), "v"(o2) : "memory");   // all three performed ...
+            atomicExch(&s->state, 2u);                                                    // ... before the slot opens
             inserted = true;
             result = slot;
             done = true;
         } else if (st == 2u) {
-            const unsigned long long a = __hip_atomic_load(&s->key_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long b = __hip_atomic_load(&s->key_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long a = atomicAdd(&s->key_lo, 0ull), b = atomicAdd(&s->key_hi, 0ull);
             if (a == klo && b == khi) {
                 atomicMin(&s->first, idx);
                 result = slot;
