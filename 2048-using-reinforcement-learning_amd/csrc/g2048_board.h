@@ -224,20 +224,27 @@ G2048_HD Board move_env_sel(const Board &b, const DirSel &s, uint32_t &gain, uin
 // Both moves of one axis at once (beam kernel): vertical = (UP, DOWN), horizontal = (LEFT, RIGHT). One transpose in,
 // two slides (the second on the reversed line order), two transposes out -- cheaper than two independent moves.
 // Env semantics for both results; the agent's DOWN quirk is applied by the caller.
-G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev)
+// merges_fwd / merges_rev: merge events of the two moves (each frees one cell).
+G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev, uint32_t &merges_fwd, uint32_t &merges_rev)
 {
     const Board t = transpose(b);
     const uint32_t x0 = vertical ? b.w[0] : t.w[0], x1 = vertical ? b.w[1] : t.w[1];
     const uint32_t x2 = vertical ? b.w[2] : t.w[2], x3 = vertical ? b.w[3] : t.w[3];
-    uint32_t F[4] = {x0, x1, x2, x3}, R[4] = {x3, x2, x1, x0}, m;
-    (void)slide_lines(F, m);
-    (void)slide_lines(R, m);
+    uint32_t F[4] = {x0, x1, x2, x3}, R[4] = {x3, x2, x1, x0};
+    (void)slide_lines(F, merges_fwd);
+    (void)slide_lines(R, merges_rev);
     const Board f = {{F[0], F[1], F[2], F[3]}}, r = {{R[3], R[2], R[1], R[0]}};
     const Board ft = transpose(f), rt = transpose(r);
     fwd.w[0] = vertical ? f.w[0] : ft.w[0]; fwd.w[1] = vertical ? f.w[1] : ft.w[1];
     fwd.w[2] = vertical ? f.w[2] : ft.w[2]; fwd.w[3] = vertical ? f.w[3] : ft.w[3];
     rev.w[0] = vertical ? r.w[0] : rt.w[0]; rev.w[1] = vertical ? r.w[1] : rt.w[1];
     rev.w[2] = vertical ? r.w[2] : rt.w[2]; rev.w[3] = vertical ? r.w[3] : rt.w[3];
+}
+
+G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev)
+{
+    uint32_t mf, mr;
+    move_axis(b, vertical, fwd, rev, mf, mr);
 }
 
 // BeamSearchAgent._make_move (agents/beam_search_agent.py:194-258): LEFT/UP/RIGHT

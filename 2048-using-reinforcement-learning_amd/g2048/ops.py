@@ -65,7 +65,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = ((L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
-            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 3) << 8))
+            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 7) << 8) | (((int(tune) >> 4) & 3) << 16))
     act_ptr = None if random_actions else actions.data_ptr()
     if keyblock is not None:        # keys (and so seed / step index) come from the device key block
         L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),
@@ -291,6 +291,10 @@ def remember_shaping(seen, next_boards, state_maxcode, flags, env_reward, out=No
     L.require_device_tensor(out, torch.float64, None, "out")
     if n == 0:
         return (out, torch.empty(0, dtype=torch.uint8, device=dev)) if want_novel else out
+
+    def aligned(t, a):      # slices of larger tensors are contiguous but may start anywhere; the kernels use 16-byte loads
+        return t if t.data_ptr() % a == 0 else t.clone()
+    next_boards, flags, env_reward = aligned(next_boards, 16), aligned(flags, 16), aligned(env_reward, 8)
     seen.reserve(n)
     lib, st = L.lib(), L.stream_ptr(dev)
     ws = torch.empty(int(lib.g2048_shaping_scan_workspace(n)), dtype=torch.uint8, device=dev)
@@ -380,7 +384,7 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
                     seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
-                    out=None, one_wave_per_game=False):
+                    out=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
     Returns (actions uint8, probs float32[, expanded int32])."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
@@ -401,7 +405,7 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     head = (roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None, actions.data_ptr(), probs.data_ptr(),
             expanded.data_ptr() if expanded is not None else None, int(width), int(depth), int(early_threshold),
             int(mid_threshold))
-    tail = (L.u64(game_id_base), n, (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.BEAM_ONE_WAVE_PER_GAME if one_wave_per_game else 0),
+    tail = (L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0,
             L.stream_ptr(dev))
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)

@@ -84,12 +84,16 @@ def cpu_info():
     return {"cpu_model": model, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
 
 
+_IN_GRAPH_EVENTS = [True]        # cleared the first time a capture with timing events in it is refused
+
+
 def graph_of(fn, dev, with_events=True):
     """Capture fn() into a hipGraph on a side stream (thread_local capture mode: with a process group alive the RCCL
     watchdog thread issues event queries that would invalidate a global-mode capture). Returns (graph, ev0, ev1) where the
     two events are recorded as the first and the last node of the graph (None if this torch / HIP cannot record timing
     events inside a capture); (None, None, None) if capture is unavailable."""
     ev0 = ev1 = None
+    with_events = with_events and _IN_GRAPH_EVENTS[0]
     try:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -112,15 +116,21 @@ def graph_of(fn, dev, with_events=True):
                                                                 type(exc).__name__, exc), file=sys.stderr)
         torch.cuda.synchronize()
         if with_events:                 # retry without in-graph events before giving the graph up
+            _IN_GRAPH_EVENTS[0] = False
             return graph_of(fn, dev, with_events=False)
         return None, None, None
 
 
 def timed_replay(graph, ev0, ev1, eager, reps=1):
-    """GPU time of one replay (ms), best of `reps`: in-graph events if there are any, else an event pair around the launch."""
+    """GPU time of one replay (ms), best of `reps`: in-graph events if there are any; else an event pair around a replay
+    that is queued directly behind another one (so that the host's graph-launch latency is not inside the pair)."""
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best = None
     for _ in range(reps):
+        if graph is not None:
+            graph.replay()
+        else:
+            eager()
         a.record()
         if graph is not None:
             graph.replay()
@@ -229,15 +239,33 @@ def main():
     torch.cuda.synchronize()
     outer_ms = o0.elapsed_time(o1)
     timing = "HIP event pair on the launch stream around the K timed launches / K"
-    kernel_s = outer_ms * 1e-3 / K
+    kernel_s = region_s = outer_ms * 1e-3 / K
     if graph is not None and ev0 is not None:
         try:
             kernel_s = ev0.elapsed_time(ev1) * 1e-3 / K
-            timing = ("HIP events recorded inside the hipGraph (first and last node, launch stream) around the K timed "
-                      "launches / K; the pair around the graph launch, host launch latency included, gave %.3f us"
-                      % (outer_ms * 1e3 / K))
+            timing = "HIP events recorded inside the hipGraph (first and last node, launch stream) around the K timed launches / K"
         except Exception as exc:        # noqa: BLE001
             print("bench.py: in-graph events unusable (%s)" % exc, file=sys.stderr)
+    elif graph is not None:
+        # torch on ROCm refuses timing events inside a capture ("External events are disallowed in rocm"), and the pair
+        # around a graph launch that starts from an idle stream also spans the host's launch latency (~10-20 us, a visible
+        # share of K = 20 launches). So the same graph of the same K launches is replayed twice back to back and the pair
+        # brackets the SECOND replay, whose launches are already queued behind the first when the GPU reaches them:
+        # what is left between the two events is the K kernels. The pair around the timed region itself is reported too.
+        best = None
+        for _ in range(3):
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            graph.replay()
+            q0.record()
+            graph.replay()
+            q1.record()
+            torch.cuda.synchronize()
+            ms = q0.elapsed_time(q1)
+            best = ms if best is None else min(best, ms)
+        kernel_s = best * 1e-3 / K
+        timing = ("HIP event pair on the launch stream around a replay of the timed region's hipGraph (the same K launches) queued "
+                  "directly behind another replay, / K; the pair around the timed region itself, which starts from an idle stream "
+                  "and so includes the graph's host launch latency, gave %.3f us per launch" % (region_s * 1e6))
     elapsed = gdist.max_over_ranks(elapsed, dev)    # ... and the job's time is the slowest rank's
 
     # ---- final metrics reduction: all-gather of per-board scores (config 5), timed separately
@@ -294,6 +322,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "step_kernel<false,false,1,256>", "kernel_us": kernel_s * 1e6,
+                     "kernel_us_timed_region_pair": region_s * 1e6,
                      "algorithmic_bytes_per_launch": n * STEP_BYTES_F32, "timing": timing,
                      "note": "LLC-resident working set at this size; the kernel is VALU-issue bound (DESIGN.md 3)"},
     }
@@ -372,7 +401,7 @@ def main():
                           "value": total_exp / bsec, "unit": "expansions/s",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
-                          "kernel": "beam_shared_kernel (4 games per 256-thread block)"}
+                          "kernel": "beam_kernel<2> (one wavefront per game, radix-select top-k)"}
         # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
         # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
         # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)

@@ -53,7 +53,8 @@ enum {
                                           draw(seed, SYNTH_ACTION, step_index, id) >> 30, exactly what g2048_synth_actions
                                           writes for the same (seed, step_index, id) */
 
-/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4 */
+/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4;
+ * bit 10 (f32 reward, no auto-reset only) selects the direction handling by per-lane selects instead of the selector table */
 #define G2048_STEP_TUNE_SHIFT  8
 
 /* opts of g2048_valid_moves */
@@ -76,10 +77,6 @@ enum {
 
 /* opts of g2048_beam_get_action */
 #define G2048_BEAM_FIXED_DOWN  0x01u   /* use the true DOWN move instead of the reference's rot180 quirk (not parity) */
-
-#define G2048_BEAM_ONE_WAVE_PER_GAME 0x02u /* tuning / A-B only (results identical): widths 17..20 normally run four games per
-                                            256-thread block with the leftover children of all four handled by one wavefront;
-                                            this forces the one-wavefront-per-game kernel every other width uses */
 
 #define G2048_BEAM_MAX_WIDTH   128
 

@@ -150,20 +150,16 @@ def test_beam_wide_beams_vs_oracle(ops, oracle, width, depth, n):
     assert int(oe.max()) > 64 * 4          # more than four passes' worth of children on some level sum
 
 
-@pytest.mark.parametrize("width", [17, 18, 19, 20])
-@pytest.mark.parametrize("n", [1, 3, 4, 4097])
-def test_beam_four_games_per_block_equals_one_wave_per_game(ops, oracle, width, n):
-    """Widths 17..20 run four games per block with shared leftover handling and a radix-select top-k; the
-    one-wavefront-per-game kernel (G2048_BEAM_ONE_WAVE_PER_GAME) and the oracle must agree with it on everything --
-    ragged game counts, dead roots, single-move roots, caller masks included."""
-    hb = np.concatenate([oracle.synth_boards(n - n // 3, seed=900 + width, p_empty=0.2, max_code=9),
+@pytest.mark.parametrize("width,depth", [(1, 8), (7, 30), (16, 30), (17, 30), (20, 30), (32, 12), (50, 10), (128, 6)])
+@pytest.mark.parametrize("n", [1, 777])
+def test_beam_widths_dead_roots_huge_tiles_masks(ops, oracle, width, depth, n):
+    """Every block shape (1 / 2 / 4 / 8 wavefronts per game) against the oracle: dead roots, single-move roots, huge tiles,
+    caller masks, a single game and a ragged batch."""
+    hb = np.concatenate([oracle.synth_boards(n - n // 3, seed=900 + width, p_empty=0.2, max_code=17),
                          oracle.synth_boards(n // 3, seed=901 + width, p_empty=0.0, max_code=3)])
     for mask in (None, dev(oracle.valid_moves_batch(hb, False))):
-        a, p, e = ops.beam_get_action(dev(hb), width, 30, mask, seed=21, step_index=5, game_id_base=(1 << 33) + 9, want_expanded=True)
-        b, q, f = ops.beam_get_action(dev(hb), width, 30, mask, seed=21, step_index=5, game_id_base=(1 << 33) + 9, want_expanded=True,
-                                      one_wave_per_game=True)
-        assert bool((a == b).all()) and bool((p == q).all()) and bool((e == f).all())
-        oa, op, oe = oracle.beam_batch(hb, width, 30, mask=None if mask is None else mask.cpu().numpy(), seed=21, step_index=5,
+        a, p, e = ops.beam_get_action(dev(hb), width, depth, mask, seed=21, step_index=5, game_id_base=(1 << 33) + 9, want_expanded=True)
+        oa, op, oe = oracle.beam_batch(hb, width, depth, mask=None if mask is None else mask.cpu().numpy(), seed=21, step_index=5,
                                        game_id_base=(1 << 33) + 9)
         assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
         assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
