@@ -19,16 +19,19 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=
     by = defaultdict(list)
     meta = {}
     for row in csv.DictReader(open(f)):
-        name = row.get("Kernel_Name", "")
+        # one line per (kernel, launch size): a kernel launched at several sizes has several average durations
+        grid = row.get("Grid_Size") or row.get("Grid_Size_X")
+        name = row.get("Kernel_Name", "") + ("  [grid %s]" % grid if grid else "")
         by[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-        meta[name] = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
+        meta[name] = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), grid,
+                      row.get("Workgroup_Size") or row.get("Workgroup_Size_X"))
     print("== kernel trace:", os.path.relpath(f, d))
     for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         if flt and flt not in name:
             continue
         v.sort()
-        print("  %-90s n=%d avg_ns=%.0f med_ns=%d min_ns=%d max_ns=%d vgpr=%s sgpr=%s lds=%s grid=%s wg=%s" % (
-            name[:90], len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[-1], *meta[name]))
+        print("  %-118s n=%d avg_ns=%.0f med_ns=%d min_ns=%d max_ns=%d vgpr=%s sgpr=%s lds=%s grid=%s wg=%s" % (
+            name[:60] + " .. " + name[-52:] if len(name) > 118 else name, len(v), sum(v) / len(v), v[len(v) // 2], v[0], v[-1], *meta[name]))
 for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
     acc = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(f)):
