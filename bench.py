@@ -408,7 +408,7 @@ def main():
                           "value": total_exp / bsec, "unit": "expansions/s",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
-                          "kernel": "beam_kernel<2> (one wavefront per game, radix-select top-k)"}
+                          "kernel": "beam_kernel<2> (one wavefront per game, two 64-child passes per level)"}
         # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
         # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
         # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
@@ -471,13 +471,25 @@ def main():
                 h = self.fc(self.enc(self.emb(x.view(x.shape[0], 16, 1))).reshape(x.shape[0], -1))
                 return torch.softmax(self.actor(h), -1), self.critic(h)
 
+        class ActorCritic(nn.Module):       # the MLP shapes agents/ppo_agent.py:61-136 actually uses (16-256-128-64-4 / -1,
+            def __init__(self):             # BatchNorm + ReLU, eval mode), stock torch, random init
+                super().__init__()
+                def trunk():
+                    return nn.Sequential(nn.Linear(16, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 128), nn.BatchNorm1d(128),
+                                         nn.ReLU(), nn.Linear(128, 64), nn.BatchNorm1d(64), nn.ReLU())
+                self.actor, self.critic = nn.Sequential(trunk(), nn.Linear(64, 4)), nn.Sequential(trunk(), nn.Linear(64, 1))
+
+            def forward(self, x):
+                return torch.softmax(self.actor(x), -1), self.critic(x)
+
         class Uniform(nn.Module):           # no network: isolates the env side of the rollout
             def forward(self, x):
                 return torch.full((x.shape[0], 4), 0.25, device=x.device)
 
         torch.manual_seed(0)
         rres = {}
-        for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("uniform_policy_env_only", Uniform())):
+        for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("mlp_actor_critic_policy", ActorCritic().to(dev).eval()),
+                          ("uniform_policy_env_only", Uniform())):
             rc = RolloutCollector(65536, 128, pol, device=dev, seed=SEED)
             rc.collect()                    # includes the one-time graph capture
             rc.collect()
@@ -493,7 +505,10 @@ def main():
             rres[name + "_graph"] = rc._graph is not None
         result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps: policy -> g2048_rollout_step (sample + step + next "
                                        "obs + next mask in one launch, auto-reset), the T-step loop replayed from one hipGraph",
-                             "unit": "env-steps/s", **rres}
+                             "unit": "env-steps/s", **rres,
+                             "note": "the policies are stock PyTorch-ROCm modules (the consumers of the rollout, not part of the hot "
+                                     "path): the reference's unused 16-token transformer (its time is torch's layer-norm / attention "
+                                     "kernels), the MLP actor / critic its PPO agent really uses, and no network at all"}
 
     # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
