@@ -42,7 +42,8 @@ constexpr uint32_t B80 = 0x80808080u;
 constexpr uint32_t B7F = 0x7f7f7f7fu;
 
 // RNG domains (DESIGN.md "RNG")
-enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6, DOM_POLICY = 7 };
+enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6, DOM_POLICY = 7,
+                  DOM_SIMULATE = 8 };
 
 // ---------------------------------------------------------------- intrinsics --
 // v_perm_b32: bytes of {s0:s1} (s1 = bytes 0..3, s0 = bytes 4..7) picked by the
@@ -627,6 +628,58 @@ G2048_HD SimOut simulate_successor(const Board &state, const Board &moved, uint3
     const uint32_t seen_empty = count_empty(seen);
     o.reward = reward_env_from(r, seen, tile_stats(seen, seen_empty), true, count_empty(state), seen_empty);
     o.done = game_over_counted(o.board, count_empty(o.board));
+    return o;
+}
+
+// The hybrid agent's simulate_move (agents/hybrid.py:578-629, monkey-patched onto its private copy of the env, :694-697):
+// the move (no quirk here: rot90-based, all four directions true), then up to three DISTINCT empty cells of the moved
+// board -- random.sample(empty_cells, min(3, n)) -- each as a 2-successor and a 4-successor whose reward
+// (_calculate_simulation_reward, :671-692: sum gained + new max if it rose + 0.1 per empty cell) is weighted by 0.9 / 0.1.
+// Successor k = 2 * pick + (0: tile 2, 1: tile 4). The picks are sampling without replacement: pick i is the
+// idx(h_i, n - i)-th empty cell, row-major, among those not picked before.
+struct SampledOut { Board board; double reward; };
+
+G2048_HD uint32_t sampled_pick_rank(uint32_t pick, uint32_t n_empty, uint32_t h0, uint32_t h1, uint32_t h2)
+{
+    const uint32_t r0 = ((h0 >> 16) * n_empty) >> 16;
+    if (pick == 0u) return r0;
+    uint32_t r1 = ((h1 >> 16) * (n_empty - 1u)) >> 16;
+    if (r1 >= r0) r1 += 1u;
+    if (pick == 1u) return r1;
+    uint32_t r2 = ((h2 >> 16) * (n_empty - 2u)) >> 16;
+    const uint32_t lo = r0 < r1 ? r0 : r1, hi = r0 < r1 ? r1 : r0;
+    if (r2 >= lo) r2 += 1u;
+    if (r2 >= hi) r2 += 1u;
+    return r2;
+}
+
+G2048_HD SampledOut simulate_sampled_successor(const Board &state, const Board &moved, uint32_t k, uint32_t n_empty,
+                                               uint32_t h0, uint32_t h1, uint32_t h2)
+{
+    SampledOut o;
+    const uint32_t rank = sampled_pick_rank(k >> 1, n_empty, h0, h1, h2);
+    const uint32_t code = (k & 1u) ? 2u : 1u;
+    {           // only the empty cell of row-major rank `rank` gets the tile (ranks by a byte-wise prefix sum of the zero flags)
+        const uint32_t ones = 0x01010101u;
+        uint32_t z[4], p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[r] = zflag(moved.w[r]); p[r] = (z[r] >> 7) * ones; }
+        const uint32_t o1 = p[0] >> 24, o2 = o1 + (p[1] >> 24), o3 = o2 + (p[2] >> 24);
+        const uint32_t want = (rank + 1u) * ones;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t rk = p[r] + (r == 0 ? 0u : r == 1 ? o1 : r == 2 ? o2 : o3) * ones;      // 1-based rank of every empty cell
+            const uint32_t eq = zflag(rk ^ want) & z[r];
+            o.board.w[r] = moved.w[r] | ((eq >> 7) * code);
+        }
+    }
+    const uint32_t old_max = max_code(state), mv_max = max_code(moved);
+    const uint32_t new_max = mv_max > code ? mv_max : code;
+    const uint32_t gained = 1u << code;                                           // a move conserves the tile sum (:673-675)
+    const uint32_t bonus = new_max > old_max ? (1u << new_max) : 0u;             // :678-682
+    double r = (double)(gained + bonus);
+    r = r + (double)(n_empty - 1u) * 0.1;                                         // :685, :688
+    o.reward = r * ((k & 1u) ? 0.1 : 0.9);                                        // :622, :628
     return o;
 }
 

@@ -233,6 +233,40 @@ __global__ __launch_bounds__(kBlock) void simulate_kernel(const uint4 *__restric
     if (k == 0) count[b] = (uint8_t)nsucc;
 }
 
+// the hybrid agent's sampled variant (agents/hybrid.py:578-629): 8 lanes per state, lane k < count builds successor k
+__global__ __launch_bounds__(kBlock) void simulate_sampled_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ actions,
+                                                                 uint4 *__restrict__ succ, double *__restrict__ reward,
+                                                                 uint8_t *__restrict__ done, uint8_t *__restrict__ count,
+                                                                 uint32_t k0, uint32_t k1, uint64_t id_base, size_t n)
+{
+    const size_t gidx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t b = gidx >> 3;
+    const uint32_t k = (uint32_t)gidx & 7u;
+    if (b >= n) return;
+    const Board state = load_board(boards, b);
+    uint32_t gain;
+    const Board moved = move_env(state, actions[b] & 3u, gain);
+    const uint32_t n_empty = count_empty(moved);
+    const bool valid = !same(moved, state);
+    const uint32_t picks = n_empty < 3u ? n_empty : 3u;
+    const uint32_t nsucc = (!valid || n_empty == 0u) ? 1u : 2u * picks;
+    Board ob = {{0u, 0u, 0u, 0u}};
+    double orw = 0.0;
+    uint32_t od = 0u;
+    if (!valid) { if (k == 0u) { ob = moved; orw = -1.0; } }                       // :601-603
+    else if (n_empty == 0u) { if (k == 0u) { ob = moved; od = 1u; } }            // :606-609 (a changed board always has an empty cell)
+    else if (k < nsucc) {
+        const uint64_t id = id_base + b;
+        const SampledOut o = simulate_sampled_successor(state, moved, k, n_empty, rng_draw(k0, k1, id, 0u), rng_draw(k0, k1, id, 1u),
+                                                        rng_draw(k0, k1, id, 2u));
+        ob = o.board; orw = o.reward;
+    }
+    store_board(succ, gidx, ob);
+    reward[gidx] = orw;
+    done[gidx] = (uint8_t)od;
+    if (k == 0u) count[b] = (uint8_t)nsucc;
+}
+
 // ------------------------------------------------------------------- eval -----
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ boards, const uint8_t *__restrict__ phase,
@@ -564,6 +598,22 @@ int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_
                        static_cast<const uint4 *>(boards), actions, highest_code_or_null, static_cast<uint4 *>(succ_boards_out),
                        reward_out, done_out, count_out, n);
     return check_launch("g2048_simulate_move");
+}
+
+int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void *succ_boards_out, double *reward_out,
+                                uint8_t *done_out, uint8_t *count_out, uint64_t seed, uint64_t step_index, uint64_t state_id_base,
+                                size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards || !actions || !succ_boards_out || !reward_out || !done_out || !count_out)
+        return fail(G2048_ERR_ARG, "g2048_simulate_move_sampled: null pointer");
+    if (!aligned16(boards) || !aligned16(succ_boards_out) || (reinterpret_cast<uintptr_t>(reward_out) & 7u))
+        return fail(G2048_ERR_ARG, "g2048_simulate_move_sampled: misaligned array");
+    const Keys k = rng_keys(seed, DOM_SIMULATE, step_index);
+    hipLaunchKernelGGL(simulate_sampled_kernel, dim3(blocks_for(n * 8)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(boards), actions, static_cast<uint4 *>(succ_boards_out), reward_out, done_out,
+                       count_out, k.k0, k.k1, state_id_base, n);
+    return check_launch("g2048_simulate_move_sampled");
 }
 
 int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "g2048_track_episodes": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _sz, _vp]),
     "g2048_sample_actions": (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_simulate_move": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "g2048_simulate_move_sampled": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_play_games": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp]),
     "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_unpack_i32": (_int, [_vp, _vp, _sz, _vp]),

@@ -358,6 +358,25 @@ def simulate_move(boards, actions, highest_code=None):
     return succ, reward, done.bool(), count
 
 
+def simulate_move_sampled(boards, actions, seed=0x2048, step_index=0, id_base=0):
+    """The hybrid agent's simulate_move (agents/hybrid.py:578-629) for every (board, action): up to three sampled empty
+    cells x {2, 4}, rewards weighted 0.9 / 0.1. Returns (succ uint8 (n,8,16), reward float64 (n,8), done bool (n,8),
+    count uint8 (n,)); only the first count[i] slots of row i are successors."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    n = boards.shape[0]
+    if actions.shape[0] != n:
+        raise ValueError("g2048: actions length must equal the number of boards")
+    dev = boards.device
+    succ = torch.empty((n, 8, 16), dtype=torch.uint8, device=dev)
+    reward = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    done = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+    count = torch.empty(n, dtype=torch.uint8, device=dev)
+    L.call(dev, L.lib().g2048_simulate_move_sampled, boards.data_ptr(), actions.data_ptr(), succ.data_ptr(), reward.data_ptr(),
+           done.data_ptr(), count.data_ptr(), L.u64(seed), L.u64(step_index), L.u64(id_base), n, L.stream_ptr(dev))
+    return succ, reward, done.bool(), count
+
+
 def pack(tiles, out=None):
     """int32 (n,16) real tile values (the reference's state layout) -> packed codes."""
     L.require_device_tensor(tiles, torch.int32, (16,), "tiles")

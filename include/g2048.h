@@ -148,6 +148,17 @@ int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_
                         void *succ_boards_out, double *reward_out, uint8_t *done_out, uint8_t *count_out,
                         size_t n, void *stream);
 
+/* The hybrid agent's simulate_move (agents/hybrid.py:578-629, the function it monkey-patches onto its own copy of the
+ * env, :694-697) for n (state, action) pairs: the move, then up to three distinct empty cells of the moved board
+ * (random.sample), each as a 2-successor and a 4-successor whose reward (_calculate_simulation_reward, :671-692) is
+ * weighted by 0.9 / 0.1. Outputs are 8 slots per state: succ_boards_out n*8 boards, reward_out n*8 f64, done_out n*8
+ * bytes; count_out[i] = valid slots: 1 for a move that changes nothing (the board itself, reward -1.0), else 2 * min(3,
+ * empty cells), successor 2j / 2j+1 = pick j with a 2 / a 4. Pick j of state i is the idx(h_j, n_empty - j)-th empty
+ * cell (row-major) not picked before, h_j = draw (seed, SIMULATE, step_index, state_id_base + i, j). */
+int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void *succ_boards_out, double *reward_out,
+                                uint8_t *done_out, uint8_t *count_out, uint64_t seed, uint64_t step_index,
+                                uint64_t state_id_base, size_t n, void *stream);
+
 /* The reference's evaluation loop (run_evaluation.py:48-69, evaluate_beam_search.py:16-98) fused per game: every game
  * (one wavefront) alternates BeamSearchAgent.get_action (no caller mask) and Game2048Env.step from boards_inout /
  * score_inout until it is over or max_moves is reached, entirely on the device. Move t of game g uses the draws of

@@ -597,6 +597,131 @@ double g2048o_ppo_heuristic(const int32_t b[16])
  * regression :249-251 (unreachable), novelty :259-262 -- contribute 0 here):
  *   reward += 0.1 * sum(log2(t) for t in sorted(next_state)[-4:] if t > 0)      :254-256
  *   reward += 0.3 * evaluate_heuristic(next_state)                               :265-266          */
+/* ---- the hybrid agent's simulate_move (agents/hybrid.py:578-692; patched onto its own copy of the env, :694-697) ---- */
+static void hybrid_move_left(int32_t g[4][4])                                     /* _simulate_move_left, :631-669 */
+{
+    for (int i = 0; i < 4; ++i) {
+        int32_t nz[4]; int n = 0;
+        for (int j = 0; j < 4; ++j) if (g[i][j] != 0) nz[n++] = g[i][j];
+        if (n == 0) continue;
+        int32_t out[4] = {0, 0, 0, 0}; int m = 0, skip = 0;
+        for (int j = 0; j < n; ++j) {
+            if (skip) { skip = 0; continue; }
+            if (j + 1 < n && nz[j] == nz[j + 1]) { out[m++] = nz[j] * 2; skip = 1; }
+            else out[m++] = nz[j];
+        }
+        for (int j = 0; j < 4; ++j) g[i][j] = out[j];
+    }
+}
+
+static void rot90_ccw(int32_t g[4][4], int times)                                  /* np.rot90(m, k) */
+{
+    for (int t = 0; t < times; ++t) {
+        int32_t r[4][4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r[i][j] = g[j][3 - i];
+        memcpy(g, r, sizeof r);
+    }
+}
+
+static double hybrid_reward(const int32_t nb[16], const int32_t ob[16])            /* _calculate_simulation_reward, :671-692 */
+{
+    int64_t old_sum = 0, new_sum = 0; int32_t old_max = ob[0], new_max = nb[0]; int zeros = 0;
+    for (int i = 0; i < 16; ++i) {
+        old_sum += ob[i]; new_sum += nb[i];
+        if (ob[i] > old_max) old_max = ob[i];
+        if (nb[i] > new_max) new_max = nb[i];
+        zeros += nb[i] == 0;
+    }
+    const int64_t merge_reward = new_sum - old_sum;
+    const int64_t max_tile_bonus = new_max > old_max ? new_max : 0;
+    const double empty_bonus = (double)zeros * 0.1;
+    return (double)(merge_reward + max_tile_bonus) + empty_bonus;
+}
+
+/* picks[j]: index into the row-major list of empty cells of the moved board (what random.sample returns, in its order).
+ * Returns the number of (successor, reward, done) triples; succ must hold 6 boards. */
+int g2048o_hybrid_simulate_move(const int32_t board[16], int action, const int *picks, int32_t *succ, double *reward, uint8_t *done)
+{
+    int32_t g[4][4];
+    memcpy(g, board, sizeof g);
+    if (action == 0) hybrid_move_left(g);                                         /* :588-601 */
+    else if (action == 1) { rot90_ccw(g, 1); hybrid_move_left(g); rot90_ccw(g, 3); }
+    else if (action == 2) { for (int i = 0; i < 4; ++i) { int32_t t = g[i][0]; g[i][0] = g[i][3]; g[i][3] = t; t = g[i][1]; g[i][1] = g[i][2]; g[i][2] = t; }
+                            hybrid_move_left(g);
+                            for (int i = 0; i < 4; ++i) { int32_t t = g[i][0]; g[i][0] = g[i][3]; g[i][3] = t; t = g[i][1]; g[i][1] = g[i][2]; g[i][2] = t; } }
+    else if (action == 3) { rot90_ccw(g, 3); hybrid_move_left(g); rot90_ccw(g, 1); }
+    const int32_t *m = &g[0][0];
+    if (memcmp(m, board, 16 * sizeof(int32_t)) == 0) {                              /* :604-608 */
+        memcpy(succ, m, 16 * sizeof(int32_t)); reward[0] = -1.0; done[0] = 0;
+        return 1;
+    }
+    int empty[16], n = 0;
+    for (int i = 0; i < 16; ++i) if (m[i] == 0) empty[n++] = i;                     /* :611 row-major */
+    if (n == 0) { memcpy(succ, m, 16 * sizeof(int32_t)); reward[0] = 0.0; done[0] = 1; return 1; }     /* :612-614 */
+    const int sample_size = n < 3 ? n : 3;                                          /* :620 */
+    int k = 0;
+    for (int j = 0; j < sample_size; ++j) {                                         /* :623-633 */
+        const int pos = empty[picks[j]];
+        for (int four = 0; four < 2; ++four) {
+            int32_t *nb = succ + 16 * k;
+            memcpy(nb, m, 16 * sizeof(int32_t));
+            nb[pos] = four ? 4 : 2;
+            reward[k] = hybrid_reward(nb, board) * (four ? 0.1 : 0.9);
+            done[k] = 0;
+            ++k;
+        }
+    }
+    return k;
+}
+
+/* the product's draw -> picks mapping (sampling without replacement, see include/g2048.h): pick j = the idx(h_j, n - j)-th
+ * empty cell among those not picked before; returned as indices into the ORIGINAL empty list */
+void g2048o_sample_picks(const uint32_t h[3], int n_empty, int picks[3])
+{
+    int taken[3]; int nt = 0;
+    const int k = n_empty < 3 ? n_empty : 3;
+    for (int j = 0; j < k; ++j) {
+        int r = (int)g2048o_draw_index(h[j], (uint32_t)(n_empty - j));
+        /* r-th among the untaken: walk the original order */
+        int idx = -1;
+        for (int c = 0; c < n_empty; ++c) {
+            int used = 0;
+            for (int t = 0; t < nt; ++t) used |= taken[t] == c;
+            if (used) continue;
+            if (r-- == 0) { idx = c; break; }
+        }
+        picks[j] = idx; taken[nt++] = idx;
+    }
+}
+
+void g2048o_hybrid_simulate_batch(const uint8_t *boards, const uint8_t *actions, uint8_t *succ, double *reward, uint8_t *done,
+                                  uint8_t *count, uint64_t seed, uint64_t step_index, uint64_t id_base, size_t n)
+{
+    uint32_t k0, k1;
+    g2048o_rng_keys(seed, 8u /* SIMULATE */, step_index, &k0, &k1);
+    for (size_t i = 0; i < n; ++i) {
+        int32_t b[16], m[16], sc;
+        g2048o_unpack(boards + 16 * i, b, 1);
+        memcpy(m, b, sizeof m);
+        g2048o_env_move(m, actions[i] & 3, &sc);
+        int ne = 0;
+        for (int c = 0; c < 16; ++c) ne += m[c] == 0;
+        uint32_t h[3];
+        for (uint32_t j = 0; j < 3; ++j) h[j] = g2048o_rng_draw(k0, k1, id_base + i, j);
+        int picks[3] = {0, 0, 0};
+        if (ne > 0) g2048o_sample_picks(h, ne, picks);
+        int32_t s6[6 * 16]; double r6[6]; uint8_t d6[6];
+        const int k = g2048o_hybrid_simulate_move(b, actions[i] & 3, picks, s6, r6, d6);
+        memset(succ + i * 8 * 16, 0, 8 * 16); 
+        for (int q = 0; q < 8; ++q) { reward[i * 8 + q] = 0.0; done[i * 8 + q] = 0; }
+        for (int q = 0; q < k; ++q) {
+            g2048o_pack(s6 + 16 * q, succ + (i * 8 + q) * 16, 1);
+            reward[i * 8 + q] = r6[q]; done[i * 8 + q] = d6[q];
+        }
+        count[i] = (uint8_t)k;
+    }
+}
+
 double g2048o_ppo_shaping(const int32_t b[16], double reward_in)
 {
     int32_t s[16]; memcpy(s, b, sizeof s);

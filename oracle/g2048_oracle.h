@@ -29,7 +29,8 @@ extern "C" {
 
 /* ---- counter RNG (spec in DESIGN.md "RNG"; restated, not shared, with csrc/) ---- */
 enum { G2048O_DOM_STEP = 1, G2048O_DOM_RESET = 2, G2048O_DOM_BEAM = 3,
-       G2048O_DOM_SYNTH_BOARD = 4, G2048O_DOM_SYNTH_ACTION = 5, G2048O_DOM_EPISODE = 6 };
+       G2048O_DOM_SYNTH_BOARD = 4, G2048O_DOM_SYNTH_ACTION = 5, G2048O_DOM_EPISODE = 6,
+       G2048O_DOM_POLICY = 7, G2048O_DOM_SIMULATE = 8 };
 void     g2048o_rng_keys(uint64_t seed, uint32_t domain, uint64_t index, uint32_t *k0, uint32_t *k1);
 uint32_t g2048o_rng_draw(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr);
 /* spawn decision from one 32-bit draw: idx in [0,n), is4 */
@@ -52,6 +53,14 @@ int    g2048o_env_step(int32_t b[16], int32_t *score, int action, uint32_t h,
 void   g2048o_env_reset(int32_t b[16], uint32_t h0, uint32_t h1);               /* :29-48 */
 int    g2048o_simulate_move(const int32_t state[16], int action, int32_t highest_tile,
                             int32_t *succ, double *reward, uint8_t *done);          /* :341-387 */
+
+/* the hybrid agent's sampled simulate_move (agents/hybrid.py:578-692); picks = what random.sample returned, as indices into
+ * the row-major empty-cell list of the moved board; succ holds up to 6 boards. Returns the number of triples. */
+int    g2048o_hybrid_simulate_move(const int32_t board[16], int action, const int *picks, int32_t *succ, double *reward,
+                                   uint8_t *done);
+void   g2048o_sample_picks(const uint32_t h[3], int n_empty, int picks[3]);          /* the product's draws -> picks */
+void   g2048o_hybrid_simulate_batch(const uint8_t *boards, const uint8_t *actions, uint8_t *succ, double *reward, uint8_t *done,
+                                    uint8_t *count, uint64_t seed, uint64_t step_index, uint64_t id_base, size_t n);
 
 /* ---- beam agent (agents/beam_search_agent.py) ---- */
 void   g2048o_agent_move(const int32_t in[16], int action, int32_t out[16],

@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libg2048_oracle.so")
 
-DOM_STEP, DOM_RESET, DOM_BEAM, DOM_SYNTH_BOARD, DOM_SYNTH_ACTION, DOM_EPISODE = 1, 2, 3, 4, 5, 6
+DOM_STEP, DOM_RESET, DOM_BEAM, DOM_SYNTH_BOARD, DOM_SYNTH_ACTION, DOM_EPISODE, DOM_POLICY, DOM_SIMULATE = 1, 2, 3, 4, 5, 6, 7, 8
 EVAL_FAST, EVAL_FULL, EVAL_PPO, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING = range(8)
 
 
@@ -80,6 +80,9 @@ def lib():
                                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]),
             "g2048o_sample_action": (C.c_int, [f32p, C.c_int, C.c_uint32, f32p]),
             "g2048o_sample_batch": (None, [f32p, u8p, u8p, f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
+            "g2048o_hybrid_simulate_move": (C.c_int, [i32p, C.c_int, C.POINTER(C.c_int), i32p, f64p, u8p]),
+            "g2048o_sample_picks": (None, [u32p, C.c_int, C.POINTER(C.c_int)]),
+            "g2048o_hybrid_simulate_batch": (None, [u8p, u8p, u8p, f64p, u8p, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t]),
             "g2048o_remember_new": (C.c_void_p, []),
             "g2048o_remember_free": (None, [C.c_void_p]),
             "g2048o_remember_highest": (C.c_int32, [C.c_void_p]),
@@ -358,3 +361,36 @@ class Remember:
         lib().g2048o_remember_batch(self._st, _p(a, C.c_uint8), _p(b, C.c_uint8), _p(r, C.c_double), _p(out, C.c_double),
                                     _p(nov, C.c_uint8), a.shape[0])
         return out, nov.astype(bool)
+
+
+# ------------------------------------------- hybrid agent's simulate_move ---
+def hybrid_simulate_move(board, action, picks):
+    """agents/hybrid.py:578-629. picks: indices into the row-major empty-cell list of the moved board, in random.sample's
+    order. Returns (succ int32 (k,16), reward f64 (k,), done bool (k,))."""
+    b = _i32(board)
+    pk = (C.c_int * 3)(*([int(x) for x in picks] + [0, 0, 0])[:3])
+    succ = np.zeros((6, 16), dtype=np.int32)
+    rw = np.zeros(6, dtype=np.float64)
+    dn = np.zeros(6, dtype=np.uint8)
+    k = lib().g2048o_hybrid_simulate_move(_p(b, C.c_int32), int(action), pk, _p(succ, C.c_int32), _p(rw, C.c_double), _p(dn, C.c_uint8))
+    return succ[:k], rw[:k], dn[:k].astype(bool)
+
+
+def sample_picks(h3, n_empty):
+    h = np.ascontiguousarray(h3, dtype=np.uint32)
+    pk = (C.c_int * 3)()
+    lib().g2048o_sample_picks(_p(h, C.c_uint32), int(n_empty), pk)
+    return [pk[j] for j in range(min(3, int(n_empty)))]
+
+
+def hybrid_simulate_batch(boards, actions, seed=0x2048, step_index=0, id_base=0):
+    bi = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, 16)
+    n = bi.shape[0]
+    ac = np.ascontiguousarray(actions, dtype=np.uint8)
+    succ = np.zeros((n, 8, 16), dtype=np.uint8)
+    rw = np.zeros((n, 8), dtype=np.float64)
+    dn = np.zeros((n, 8), dtype=np.uint8)
+    cnt = np.zeros(n, dtype=np.uint8)
+    lib().g2048o_hybrid_simulate_batch(_p(bi, C.c_uint8), _p(ac, C.c_uint8), _p(succ, C.c_uint8), _p(rw, C.c_double), _p(dn, C.c_uint8),
+                                       _p(cnt, C.c_uint8), seed, step_index, id_base, n)
+    return succ, rw, dn.astype(bool), cnt

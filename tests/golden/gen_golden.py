@@ -584,10 +584,54 @@ def gen_remember():
                         final_seen=np.int64(len(ppo.seen_states)))
 
 
+def gen_simulate_sampled():
+    """agents/hybrid.py:578-629 -- the simulate_move the hybrid agent patches onto its own copy of the env -- for a pool of
+    (board, action): the list of (next_state, weighted reward, done) it returns. random.sample is replaced by the recorded
+    draws (pick j = the idx(h_j, n - j)-th empty cell not picked before, the product's mapping)."""
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        import agents.hybrid as hyb
+    env = hyb.Game2048Env()
+    rng = np.random.default_rng(777)
+    pool = np.concatenate([random_code_boards(rng, 500, 0.30, 11), random_code_boards(rng, 200, 0.05, 4),
+                           random_code_boards(rng, 150, 0.0, 3), random_code_boards(rng, 150, 0.8, 17),
+                           random_code_boards(rng, 100, 0.5, 2)]).astype(np.uint8)
+    pool[pool.max(axis=1) == 0, 5] = 1
+    n = pool.shape[0]
+    actions = (np.arange(n) % 4).astype(np.uint8)
+    H = np.zeros((n, 3), np.uint32)
+    succ = np.zeros((n, 8, 16), np.uint8)
+    rew = np.zeros((n, 8), np.float64)
+    done = np.zeros((n, 8), np.uint8)
+    count = np.zeros(n, np.uint8)
+    cur = {}
+
+    def sample(population, k):
+        picks = O.sample_picks(cur["h"], len(population))
+        assert len(picks) == k
+        return [population[i] for i in picks]
+    real_sample = random.sample
+    random.sample = sample
+    try:
+        for i in range(n):
+            H[i] = [hashed(O.DOM_SIMULATE, 3, i, j) for j in range(3)]
+            cur["h"] = H[i]
+            res = env.simulate_move(tiles_of(pool[i]).reshape(4, 4), int(actions[i]))
+            count[i] = len(res)
+            for k, (st, r, d) in enumerate(res):
+                succ[i, k] = codes_of(st); rew[i, k] = float(r); done[i, k] = bool(d)
+    finally:
+        random.sample = real_sample
+    print("simulate_sampled", n, "counts", np.bincount(count, minlength=7))
+    np.savez_compressed(os.path.join(HERE, "simulate_sampled.npz"), board=pool, action=actions, h=H, succ=succ, reward=rew,
+                        done=done, count=count, seed=np.uint64(SEED), step_index=np.uint64(3))
+
+
 def main():
     if "--only" in sys.argv:
         what = sys.argv[sys.argv.index("--only") + 1]
-        {"remember": gen_remember}[what]()
+        {"remember": gen_remember, "simulate_sampled": gen_simulate_sampled}[what]()
         return
     O.build()
     rng = np.random.default_rng(2048)
@@ -644,6 +688,7 @@ def main():
                                    random_code_boards(np.random.default_rng(322), 25, 0.4, 8)]).astype(np.uint8))
     gen_episodes()
     gen_remember()
+    gen_simulate_sampled()
     print("done in %.1fs" % (time.time() - t0))
 
 

@@ -110,6 +110,29 @@ void hs_simulate(const uint8_t *in, const uint8_t *actions, const uint8_t *hc, u
     }
 }
 
+// the hybrid agent's sampled simulate_move: 8 slots per state, as the kernel lays them out
+void hs_simulate_sampled(const uint8_t *in, const uint8_t *actions, const uint32_t *h3, uint8_t *succ, double *reward, uint8_t *done,
+                         uint8_t *count, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const Board state = ld(in + 16 * i);
+        uint32_t gain;
+        const Board moved = move_env(state, actions[i] & 3u, gain);
+        const uint32_t ne = count_empty(moved);
+        const bool valid = !same(moved, state);
+        const uint32_t picks = ne < 3u ? ne : 3u;
+        const uint32_t ns = (!valid || ne == 0u) ? 1u : 2u * picks;
+        count[i] = (uint8_t)ns;
+        for (uint32_t k = 0; k < 8; ++k) { st(succ + (i * 8 + k) * 16, Board{{0, 0, 0, 0}}); reward[i * 8 + k] = 0.0; done[i * 8 + k] = 0; }
+        if (!valid) { st(succ + i * 8 * 16, moved); reward[i * 8] = -1.0; continue; }
+        if (ne == 0u) { st(succ + i * 8 * 16, moved); done[i * 8] = 1; continue; }
+        for (uint32_t k = 0; k < ns; ++k) {
+            const SampledOut o = simulate_sampled_successor(state, moved, k, ne, h3[3 * i], h3[3 * i + 1], h3[3 * i + 2]);
+            st(succ + (i * 8 + k) * 16, o.board); reward[i * 8 + k] = o.reward;
+        }
+    }
+}
+
 void hs_sample(const float *probs, const uint8_t *mask, const uint32_t *h, uint8_t *actions, float *prob, size_t n)
 {
     for (size_t i = 0; i < n; ++i)

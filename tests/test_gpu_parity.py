@@ -339,6 +339,22 @@ def test_simulate_move_f4(ops, oracle):
     assert np.array_equal(env.board, before[0]) and env.score == before[1] and env.highest_tile == before[2]
 
 
+def test_simulate_move_sampled(ops, oracle):
+    """g2048_simulate_move_sampled (the hybrid agent's simulate_move, agents/hybrid.py:578-629): golden vectors taken from the
+    reference, then 200k random (state, action) pairs against the oracle."""
+    g = load_golden("simulate_sampled.npz")
+    succ, rw, dn, cnt = ops.simulate_move_sampled(dev(g["board"]), dev(g["action"]), seed=int(g["seed"]), step_index=int(g["step_index"]))
+    assert np.array_equal(host(cnt), g["count"]) and np.array_equal(host(succ), g["succ"])
+    assert np.array_equal(host(rw), g["reward"]) and np.array_equal(host(dn), g["done"].astype(bool))
+    n = 200000
+    hb = np.concatenate([oracle.synth_boards(n // 2, seed=31, p_empty=0.3, max_code=12), oracle.synth_boards(n // 2, seed=32, p_empty=0.85, max_code=17)])
+    ha = oracle.synth_actions(n, seed=31, step_index=0)
+    succ, rw, dn, cnt = ops.simulate_move_sampled(dev(hb), dev(ha), seed=77, step_index=9, id_base=(1 << 40) + 3)
+    os_, orw, odn, ocnt = oracle.hybrid_simulate_batch(hb, ha, seed=77, step_index=9, id_base=(1 << 40) + 3)
+    assert np.array_equal(host(cnt), ocnt) and np.array_equal(host(succ), os_)
+    assert np.array_equal(host(rw), orw) and np.array_equal(host(dn), odn)
+
+
 @pytest.mark.parametrize("p_empty,max_code", [(0.0, 2), (0.02, 4), (0.3, 17), (0.7, 17), (0.95, 3)])
 def test_step_fuzz_all_modes(ops, oracle, p_empty, max_code):
     """Differential fuzz: 2 Mi boards per distribution (dense low tiles ... sparse huge tiles), every template mode of

@@ -194,6 +194,22 @@ def test_simulate_move_vs_golden(hs):
     assert np.array_equal(dn, g["done"])
 
 
+def test_simulate_move_sampled_vs_golden(hs):
+    """The hybrid agent's sampled simulate_move (agents/hybrid.py:578-629): the SWAR successor / reward arithmetic against
+    what the reference returned for the same picks."""
+    g = load_golden("simulate_sampled.npz")
+    b = np.ascontiguousarray(g["board"]); n = b.shape[0]
+    succ = np.zeros((n, 8, 16), np.uint8); rw = np.zeros((n, 8), np.float64)
+    dn = np.zeros((n, 8), np.uint8); cnt = np.zeros(n, np.uint8)
+    hs.hs_simulate_sampled(p(b), p(np.ascontiguousarray(g["action"])), p(np.ascontiguousarray(g["h"]), C.c_uint32), p(succ),
+                           p(rw, C.c_double), p(dn), p(cnt), C.c_size_t(n))
+    assert np.array_equal(cnt, g["count"])
+    assert np.array_equal(succ, g["succ"])
+    assert np.array_equal(rw, g["reward"])
+    assert np.array_equal(dn, g["done"])
+    assert set(np.unique(cnt)) == {1, 2, 4, 6}
+
+
 def test_sample_action_vs_oracle_and_distribution(hs, oracle):
     rng = np.random.default_rng(3)
     n = 200000

@@ -219,3 +219,17 @@ def test_remember_sequential_golden(oracle):
     assert np.array_equal(np.concatenate(parts), g["reward_out"])
     # the two stateful terms really fire in the fixture
     assert 0 < int(nov.sum()) < n and int(g["done"].sum()) > 0
+
+
+def test_hybrid_simulate_move_sampled_golden(oracle):
+    """The oracle's restatement of the hybrid agent's simulate_move (agents/hybrid.py:578-692) against the reference's output
+    for recorded random.sample picks; also the draw -> picks mapping is a sampling without replacement."""
+    g = load_golden("simulate_sampled.npz")
+    succ, rw, dn, cnt = oracle.hybrid_simulate_batch(g["board"], g["action"], seed=int(g["seed"]), step_index=int(g["step_index"]))
+    assert np.array_equal(cnt, g["count"]) and np.array_equal(succ, g["succ"])
+    assert np.array_equal(rw, g["reward"]) and np.array_equal(dn, g["done"].astype(bool))
+    rng = np.random.default_rng(0)
+    for n_empty in range(1, 17):
+        for _ in range(50):
+            picks = oracle.sample_picks(rng.integers(0, 2**32, 3, dtype=np.uint64).astype(np.uint32), n_empty)
+            assert len(picks) == min(3, n_empty) == len(set(picks)) and all(0 <= x < n_empty for x in picks)
