@@ -93,6 +93,8 @@ def graph_of(fn, dev, with_events=True):
     two events are recorded as the first and the last node of the graph (None if this torch / HIP cannot record timing
     events inside a capture); (None, None, None) if capture is unavailable."""
     ev0 = ev1 = None
+    if getattr(torch.version, "hip", None):
+        _IN_GRAPH_EVENTS[0] = False     # known: "External events are disallowed in rocm" -- do not even start such a capture
     with_events = with_events and _IN_GRAPH_EVENTS[0]
     try:
         side = torch.cuda.Stream(device=dev)
@@ -577,6 +579,7 @@ def main():
         print(json.dumps(result))
     if world > 1:
         import torch.distributed as dist
+        barrier()                       # rank 0 was still verifying / printing: leave together
         dist.destroy_process_group()
     return 0
 
