@@ -147,15 +147,12 @@ G2048_HD uint32_t slide_lines(uint32_t L[4], uint32_t &merges)
     // never share a byte lane (m12 excludes m23, m01&m23 excludes ~m01), so they fold into one word.
     const uint32_t g1 = (m01 & m23) | m12, g2 = m23 & ~m01;
     merges = popc(m01) + popc(g1 | g2);             // every merge frees exactly one cell
-    uint32_t gain = 0;
-    if (merges) {
-        const uint32_t G0 = pick(o0, 0u, s01), G12 = pick(o1, 0u, selof(g1)) | pick(o2, 0u, selof(g2));
-        uint32_t acc = 0;
+    // no branch on "any merge": without one both words are zero, the eight terms are 1 << 0 each and the result is 0 anyway
+    const uint32_t G0 = pick(o0, 0u, s01), G12 = pick(o1, 0u, selof(g1)) | pick(o2, 0u, selof(g2));
+    uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc += (1u << ((G0 >> (8 * k)) & 0xffu)) + (1u << ((G12 >> (8 * k)) & 0xffu));
-        gain = acc - (8u - merges);                 // every non-merged byte contributed 1 << 0
-    }
-    return gain;
+    for (int k = 0; k < 4; ++k) acc += (1u << ((G0 >> (8 * k)) & 0xffu)) + (1u << ((G12 >> (8 * k)) & 0xffu));
+    return acc - (8u - merges);                     // every non-merged byte contributed 1 << 0
 }
 
 // One move on the whole board. action: 0 LEFT, 1 UP, 2 RIGHT, 3 DOWN

@@ -12,6 +12,11 @@ import torch
 import torch.distributed as dist
 
 
+# G2048_DIST_FORCE=1: initialise the process group and run the collectives even at world size 1 (tests/test_gpu_rccl.py uses
+# it to exercise RCCL on a one-GPU box); normally a single rank takes the shortcuts below
+_FORCE = os.environ.get("G2048_DIST_FORCE") == "1"
+
+
 def world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -19,7 +24,7 @@ def world():
 def init(backend=None, device=None):
     """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
     w, r, lr = world()
-    if w > 1 and not dist.is_initialized():
+    if (w > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("G2048_DIST_BACKEND") or backend      # rehearsal override (e.g. gloo on one GPU)
         if backend is None:
@@ -50,7 +55,7 @@ def barrier():
 def all_gather_scores(scores):
     """Per-board scores of every shard, in global id order. Equal shard sizes (the benchmark's case) use one
     all_gather_into_tensor; ragged shards fall back to all_gather of padded tensors."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return scores.clone()
     if _staged(scores):
         return all_gather_scores(scores.cpu()).to(scores.device)
@@ -73,7 +78,7 @@ def all_gather_scores(scores):
 
 def reduce_metrics(metrics):
     """Sum of the per-shard metric vectors (g2048_metrics layout) over all ranks, in place."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):
         if _staged(metrics):
             h = metrics.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -84,7 +89,7 @@ def reduce_metrics(metrics):
 
 
 def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

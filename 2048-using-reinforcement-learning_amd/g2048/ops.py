@@ -65,7 +65,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = ((L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
-            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 7) << 8) | (((int(tune) >> 4) & 3) << 16))
+            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 7) << 8))
     act_ptr = None if random_actions else actions.data_ptr()
     if keyblock is not None:        # keys (and so seed / step index) come from the device key block
         L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),

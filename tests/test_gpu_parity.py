@@ -88,6 +88,18 @@ def test_step_vs_oracle_sizes(ops, oracle, n):
         assert set(np.unique(host(a))) == {0, 1, 2, 3}
 
 
+def test_step_select_direction_variant(ops, oracle):
+    """tune bit 2: the round-1 direction handling (per-lane selects), kept for A/B -- same results as the selector table."""
+    n = 300001
+    b = ops.synth_boards(n, seed=SEED + 3, device=DEV)
+    a = ops.synth_actions(n, seed=SEED + 3, step_index=0, device=DEV)
+    s1 = torch.zeros(n, dtype=torch.int32, device=DEV); s2 = torch.zeros_like(s1)
+    o1, r1, f1 = ops.step(b, a, s1, seed=SEED, step_index=4)
+    o2, r2, f2 = ops.step(b, a, s2, seed=SEED, step_index=4, tune=5)
+    assert bool((o1 == o2).all()) and bool((f1 == f2).all()) and bool((s1 == s2).all())
+    assert np.array_equal(host(r1).view(np.uint32), host(r2).view(np.uint32))
+
+
 @pytest.mark.parametrize("tune", [1, 2, 3])
 @pytest.mark.parametrize("n", [1, 1023, 4097, 300001])
 def test_step_boards_per_lane_variants(ops, oracle, tune, n):

@@ -22,7 +22,7 @@ out = torch.empty_like(boards)
 scores = torch.zeros(n, dtype=torch.int32, device=dev)
 reward = torch.empty(n, dtype=torch.float32, device=dev)
 flags = torch.empty(n, dtype=torch.uint8, device=dev)
-variants = [1, 2, 3]     # boards per lane 1 / 2 / 4     # low 2 bits: boards/lane 1/2/4; bits 2-3: block 64/128/512; bit 4: staged (2 / 4 / 8 per lane)
+variants = [1, 5, 2, 3]     # low 2 bits: boards per lane 1 / 2 / 4; bit 2: direction by per-lane selects (round-1 form)
 graphs = {}
 for v in variants:
     for t in range(3):
@@ -48,6 +48,6 @@ for r in range(ROUNDS):
 for v in variants:
     x = np.array(res[v][2:])
     us = np.median(x)
-    desc = "boards/lane %d" % [0, 1, 2, 4][v]
+    desc = "boards/lane %d%s" % ([0, 1, 2, 4][v & 3], ", select-direction" if v & 4 else "")
     print("variant %2d (%s): median %.2f us  min %.2f us  -> %.2f TB/s algorithmic, %.1f Gsteps/s" % (
         v, desc, us, x.min(), n * 46 / us / 1e6, n / us / 1e3))
