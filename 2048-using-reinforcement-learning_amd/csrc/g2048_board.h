@@ -545,6 +545,17 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
     return step_board_with(prev, [action](const Board &b, uint32_t &g, uint32_t &m) { return move_env(b, action, g, m); }, h);
 }
 
+// An action outside 0..3 moves nothing in the reference (_execute_move, environment/game_2048.py:97-114, has no branch for
+// it), so the step is an invalid move: no spawn, the -2.0 of :226-227. noop = "this lane's action is such a value".
+G2048_HD StepOut step_board_sel_noop(const Board &prev, const DirSel &sel, bool noop, uint32_t h)
+{
+    return step_board_with(prev, [&sel, noop](const Board &b, uint32_t &g, uint32_t &m) {
+        const Board r = move_env_sel(b, sel, g, m);
+        g = noop ? 0u : g; m = noop ? 0u : m;
+        return Board{{noop ? b.w[0] : r.w[0], noop ? b.w[1] : r.w[1], noop ? b.w[2] : r.w[2], noop ? b.w[3] : r.w[3]}};
+    }, h);
+}
+
 // the same step with the direction given as its selector words (see "direction by table")
 G2048_HD StepOut step_board_sel(const Board &prev, const DirSel &sel, uint32_t h)
 {

@@ -54,8 +54,8 @@ __device__ const uint32_t kDirTable[G2048_DIR_TABLE_WORDS] = G2048_DIR_TABLE_INI
 
 __device__ __forceinline__ void dir_table_to_lds(uint4 *s_dir)
 {
-    const uint32_t l = threadIdx.x & 63u;
-    if (l < G2048_DIR_TABLE_WORDS) reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];
+    const uint32_t l = threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u);          // both halves of the wave write the same 32 words:
+    reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];                    // no exec masking, no branch
 }
 
 __device__ __forceinline__ DirSel dir_sel(const uint4 *s_dir, uint32_t action)
@@ -81,7 +81,8 @@ __device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
 // board the kernel sits between the HBM and the VALU roofline, and a wave that only ever has one board
 // in flight serialises load latency -> compute -> store. A block owns 256*B consecutive boards; pass k
 // of a wave touches 64 consecutive boards (1 KiB per wave-instruction).
-template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false, bool SELECT_DIR = false>
+// NOOP_ACTIONS: action bytes above 3 move nothing, as in the reference (drop-in class); otherwise the low two bits count
+template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false, bool SELECT_DIR = false, bool NOOP_ACTIONS = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
                                                      uint4 *boards_out,
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     double *rw64 = static_cast<double *>(reward_out) + block0;
     const bool full = block0 + (size_t)(BLOCK * B) <= n;          // wave-uniform: every lane of the block is in range
     const uint32_t lim = full ? (uint32_t)(BLOCK * B) : (uint32_t)(n - block0);
+    if (B == 1 && !(full || threadIdx.x < lim)) return;       // one exec region for the whole body instead of two
     Board prev[B];
     uint32_t action[B], sc[B];
 #pragma unroll
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
         // SELECT_DIR: the round-1 formulation (per-lane selects between transposed / reversed copies), kept for A/B only
         const StepOut o = SELECT_DIR ? step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id, 0u))
-                                     : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u));
+                        : NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u))
+                                       : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u));
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
         if (AUTO_RESET) {
@@ -453,7 +456,7 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
-    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS | (7u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS | G2048_STEP_NOOP_ACTIONS | (7u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
     const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *in = static_cast<const uint4 *>(boards_in);
@@ -467,6 +470,15 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
 #define G2048_LAUNCH_STEP_B(F, A) \
     do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
          else G2048_LAUNCH_STEP(F, A, 4); } while (0)
+    if (opts & G2048_STEP_NOOP_ACTIONS) {            // reference semantics for action values outside 0..3 (drop-in class)
+        if (random_actions) return fail(G2048_ERR_ARG, "g2048_step: NOOP_ACTIONS needs explicit actions");
+#define G2048_LAUNCH_NOOP(F, A) hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, false, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, \
+                           in, actions, out, score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
+        if (f64 && ar) G2048_LAUNCH_NOOP(true, true); else if (f64) G2048_LAUNCH_NOOP(true, false);
+        else if (ar) G2048_LAUNCH_NOOP(false, true); else G2048_LAUNCH_NOOP(false, false);
+#undef G2048_LAUNCH_NOOP
+        return check_launch("g2048_step");
+    }
     if ((opts >> G2048_STEP_TUNE_SHIFT) & 4u) {      // A/B only: direction by per-lane selects, f32 reward, no auto-reset
         if (f64 || ar || random_actions) return fail(G2048_ERR_ARG, "g2048_step: the select-direction A/B variant is plain f32 only");
         hipLaunchKernelGGL((step_kernel<false, false, 1, kBlock, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, in, actions,

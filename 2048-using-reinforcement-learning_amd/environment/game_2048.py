@@ -7,8 +7,9 @@ One board living on the GPU and stepped by the same HIP kernel that steps millio
   * tile spawns come from the engine's counter RNG, not from Python's global `random`
     (the seed defaults to one draw from `random`, so `random.seed(k)` still pins a run);
   * size != 4 raises (the reference's agents hard-code 4x4: beam_search_agent.py:69,378);
-  * step(action) with an action outside 0..3 raises ValueError (the reference silently treats it as a move that
-    changes nothing; the batched kernels use the low two bits of the action byte).
+  * step(action) with an action outside 0..3 is, as in the reference (`_execute_move` has no branch for it, :97-114), a
+    move that changes nothing: invalid, no spawn, the invalid-move reward (G2048_STEP_NOOP_ACTIONS; the batched front-ends
+    use the low two bits of the action byte unless asked otherwise).
 """
 import random
 
@@ -94,11 +95,10 @@ class Game2048Env:
         return [bool((m >> a) & 1) for a in range(4)]
 
     def step(self, action):                                    # reference :170-210
-        if int(action) not in (0, 1, 2, 3):
-            raise ValueError("Game2048Env.step: action must be 0 (LEFT), 1 (UP), 2 (RIGHT) or 3 (DOWN)")
-        self._action.fill_(int(action))
+        a = int(action)
+        self._action.fill_(a if a in (0, 1, 2, 3) else 255)        # anything else moves nothing, as the reference's :97-114
         ops.step(self._boards, self._action, self._scores, self.seed, self._t, 0, out=self._boards,
-                 reward=self._reward, flags=self._flags, reward_f64=True)
+                 reward=self._reward, flags=self._flags, reward_f64=True, noop_actions=True)
         self._t += 1
         flags, reward = self._pull()
         self.game_over = bool(flags & L.FLAG_DONE)

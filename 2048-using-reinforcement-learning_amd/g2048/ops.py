@@ -35,12 +35,13 @@ def _require_scores(scores):
 
 
 def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=None, flags=None,
-         reward_f64=False, auto_reset=False, tune=0, keyblock=None):
+         reward_f64=False, auto_reset=False, tune=0, keyblock=None, noop_actions=False):
     """Game2048Env.step for every board (reference environment/game_2048.py:170-210).
 
     scores (uint32) is updated in place. Returns (boards_out, reward, flags); flags bit0 = done,
     bit1 = valid move, bits 3..7 = max log2 code. `out` may be `boards` for an in-place step.
-    actions=None: random playout, the kernel draws the uniform actions synth_actions(seed, step_index) would give."""
+    actions=None: random playout, the kernel draws the uniform actions synth_actions(seed, step_index) would give.
+    noop_actions: action values above 3 move nothing (an invalid move), as in the reference; default: low two bits count."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     n = boards.shape[0]
     random_actions = actions is None
@@ -65,7 +66,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = ((L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
-            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | ((int(tune) & 7) << 8))
+            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | (L.STEP_NOOP_ACTIONS if noop_actions else 0) | ((int(tune) & 7) << 8))
     act_ptr = None if random_actions else actions.data_ptr()
     if keyblock is not None:        # keys (and so seed / step index) come from the device key block
         L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),

@@ -53,6 +53,10 @@ enum {
                                           draw(seed, SYNTH_ACTION, step_index, id) >> 30, exactly what g2048_synth_actions
                                           writes for the same (seed, step_index, id) */
 
+#define G2048_STEP_NOOP_ACTIONS 0x08u  /* an action byte above 3 moves nothing -- an invalid move -- exactly as the reference's
+                                          _execute_move (game_2048.py:97-114) treats values other than 0..3; without this
+                                          flag only the low two bits of the byte are looked at */
+
 /* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4;
  * bit 10 (f32 reward, no auto-reset only) selects the direction handling by per-lane selects instead of the selector table */
 #define G2048_STEP_TUNE_SHIFT  8

@@ -932,7 +932,7 @@ void g2048o_step_batch(const uint8_t *boards_in, const uint8_t *actions, uint8_t
         g2048o_unpack(boards_in + i * 16, b, 1);
         int32_t score = (int32_t)score_inout[i];
         uint32_t h = g2048o_rng_draw(k0, k1, id_base + i, 0);
-        int valid = g2048o_env_step(b, &score, actions[i] & 3, h, &r, &done, NULL);
+        int valid = g2048o_env_step(b, &score, (opts & 2u) ? (int)actions[i] : (actions[i] & 3), h, &r, &done, NULL);
         uint8_t out[16];
         g2048o_pack(b, out, 1);
         uint8_t flags = (uint8_t)((done ? 1 : 0) | (valid ? 2 : 0) | (max_code16(out) << 3));

@@ -104,7 +104,8 @@ void g2048o_synth_boards(uint8_t *codes, uint64_t seed, uint64_t id_base, size_t
 void g2048o_synth_actions(uint8_t *actions, uint64_t seed, uint64_t step_index,
                           uint64_t id_base, size_t n);
 /* flags: bit0 done, bit1 valid, bits 3..7 = max log2 code after the step.
- * opts bit0: auto-reset finished boards (new episode drawn in DOM_EPISODE).    */
+ * opts bit0: auto-reset finished boards (new episode drawn in DOM_EPISODE); bit1: action bytes above 3 move
+ * nothing, as Game2048Env._execute_move (:97-114) treats them (default: the low two bits are the action).      */
 void g2048o_step_batch(const uint8_t *boards_in, const uint8_t *actions, uint8_t *boards_out,
                        uint32_t *score_inout, double *reward_out, uint8_t *flags_out,
                        uint64_t seed, uint64_t step_index, uint64_t id_base, size_t n,

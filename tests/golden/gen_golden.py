@@ -520,6 +520,30 @@ def gen_rng_pin():
     print("rng_pin", a.shape[0])
 
 
+def gen_step_noop(pool):
+    """Game2048Env.step with action values outside 0..3: _execute_move (:97-114) has no branch for them, so nothing moves."""
+    env = Game2048Env()
+    rng = np.random.default_rng(404)
+    dead = np.array([[(a if (r + c) % 2 == 0 else b) for r in range(4) for c in range(4)] for a in range(1, 6) for b in range(6, 10)], np.uint8)
+    sel = np.concatenate([pool[rng.choice(pool.shape[0], 400, replace=False)], dead])      # + 20 finished (checkerboard) boards
+    n = sel.shape[0]
+    actions = rng.choice(np.array([4, 5, 7, 100, 255], np.uint8), size=n)
+    scores_in = rng.integers(0, 50000, size=n).astype(np.int32)
+    board_out = np.zeros((n, 16), np.uint8); score_out = np.zeros(n, np.int32); reward = np.zeros(n, np.float64)
+    done = np.zeros(n, np.uint8); valid = np.zeros(n, np.uint8); consumed = np.zeros(n, np.uint8)
+    for i in range(n):
+        set_env(env, tiles_of(sel[i]), int(scores_in[i]))
+        STREAM.source = list_source([hashed(O.DOM_STEP, 6, i)])
+        STREAM.consumed = 0
+        st, r, d, info = env.step(int(actions[i]))
+        board_out[i] = codes_of(st); score_out[i] = int(info["score"]); reward[i] = float(r)
+        done[i] = bool(d); valid[i] = bool(info["valid_move"]); consumed[i] = STREAM.consumed
+    assert not valid.any() and not consumed.any() and np.array_equal(board_out, sel)
+    np.savez_compressed(os.path.join(HERE, "step_noop.npz"), board_in=sel, action=actions, score_in=scores_in, board_out=board_out,
+                        score_out=score_out, reward=reward, done=done, valid=valid)
+    print("step_noop", n, "done", int(done.sum()), "nan", int(np.isnan(reward).sum()))
+
+
 def gen_remember():
     """PPOAgent.remember (agents/ppo_agent.py:234-269) run SEQUENTIALLY by the reference over an ordered list of
     transitions, all of its terms live (highest_tile_seen and seen_states start fresh, as a new agent's do):
@@ -631,6 +655,11 @@ def gen_simulate_sampled():
 def main():
     if "--only" in sys.argv:
         what = sys.argv[sys.argv.index("--only") + 1]
+        if what == "step_noop":
+            rng = np.random.default_rng(1)
+            gen_step_noop(np.concatenate([random_code_boards(rng, 600, 0.30, 11), random_code_boards(rng, 300, 0.0, 3),
+                                          random_code_boards(rng, 300, 0.6, 17)]).astype(np.uint8))
+            return
         {"remember": gen_remember, "simulate_sampled": gen_simulate_sampled}[what]()
         return
     O.build()
@@ -689,6 +718,9 @@ def main():
     gen_episodes()
     gen_remember()
     gen_simulate_sampled()
+    rng2 = np.random.default_rng(1)
+    gen_step_noop(np.concatenate([random_code_boards(rng2, 600, 0.30, 11), random_code_boards(rng2, 300, 0.0, 3),
+                                  random_code_boards(rng2, 300, 0.6, 17)]).astype(np.uint8))
     print("done in %.1fs" % (time.time() - t0))
 
 

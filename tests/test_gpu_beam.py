@@ -96,6 +96,11 @@ def test_drop_in_classes_train_loop(ops, oracle):
     assert env.get_valid_moves() == [True, True, True, True]
     s, r, d, info = env.step(0)
     assert s[0] == 4 and info["valid_move"]
+    # an action outside 0..3 moves nothing, as in the reference (_execute_move, :97-114): invalid move, no spawn
+    before, score_before = env.board.copy(), env.score
+    s, r, d, info = env.step(7)
+    want = oracle.env_step(before.flatten(), int(score_before), 7, 0)
+    assert np.array_equal(env.board, before) and not info["valid_move"] and r == want[2] and env.score == score_before
 
 
 def test_beam_arbitrary_masks_and_random_fallback(ops):

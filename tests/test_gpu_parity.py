@@ -351,6 +351,31 @@ def test_simulate_move_f4(ops, oracle):
     assert np.array_equal(env.board, before[0]) and env.score == before[1] and env.highest_tile == before[2]
 
 
+def test_step_out_of_range_actions(ops, oracle):
+    """G2048_STEP_NOOP_ACTIONS: action bytes above 3 move nothing, as in the reference (golden), mixed with real moves in one
+    launch (oracle); without the flag the low two bits count."""
+    g = load_golden("step_noop.npz")
+    n = g["board_in"].shape[0]
+    sc = dev(g["score_in"].astype(np.int32))
+    out, rw, fl = ops.step(dev(g["board_in"]), dev(g["action"]), sc, seed=1, step_index=0, reward_f64=True, noop_actions=True)
+    assert np.array_equal(host(out), g["board_out"]) and np.array_equal(host(sc), g["score_out"])
+    assert np.array_equal(host(rw), g["reward"], equal_nan=True)
+    assert np.array_equal(host(fl) & 1, g["done"]) and not ((host(fl) >> 1) & 1).any()
+    n = 100003
+    hb = oracle.synth_boards(n, seed=8, p_empty=0.2, max_code=7)
+    ha = np.random.default_rng(8).integers(0, 9, n).astype(np.uint8)
+    for ar in (False, True):
+        s1 = torch.zeros(n, dtype=torch.int32, device=DEV)
+        o1, r1, f1 = ops.step(dev(hb), dev(ha), s1, seed=5, step_index=2, id_base=77, reward_f64=True, auto_reset=ar, noop_actions=True)
+        bo, so, ro, fo = oracle.step_batch(hb, ha, np.zeros(n, np.uint32), seed=5, step_index=2, id_base=77, opts=2 | int(ar))
+        assert np.array_equal(host(o1), bo) and np.array_equal(host(s1).astype(np.uint32), so)
+        assert np.array_equal(host(r1), ro, equal_nan=True) and np.array_equal(host(f1), fo)
+    s2 = torch.zeros(n, dtype=torch.int32, device=DEV)
+    o2, r2, f2 = ops.step(dev(hb), dev(ha), s2, seed=5, step_index=2, id_base=77, reward_f64=True)
+    bo, so, ro, fo = oracle.step_batch(hb, ha & 3, np.zeros(n, np.uint32), seed=5, step_index=2, id_base=77)
+    assert np.array_equal(host(o2), bo) and np.array_equal(host(f2), fo)
+
+
 def test_simulate_move_sampled(ops, oracle):
     """g2048_simulate_move_sampled (the hybrid agent's simulate_move, agents/hybrid.py:578-629): golden vectors taken from the
     reference, then 200k random (state, action) pairs against the oracle."""

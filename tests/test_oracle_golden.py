@@ -233,3 +233,14 @@ def test_hybrid_simulate_move_sampled_golden(oracle):
         for _ in range(50):
             picks = oracle.sample_picks(rng.integers(0, 2**32, 3, dtype=np.uint64).astype(np.uint32), n_empty)
             assert len(picks) == min(3, n_empty) == len(set(picks)) and all(0 <= x < n_empty for x in picks)
+
+
+def test_step_out_of_range_actions_golden(oracle):
+    """Action values outside 0..3 move nothing in the reference (environment/game_2048.py:97-114): the oracle's batch step
+    with that semantics (opts bit 1) against the reference's transitions."""
+    g = load_golden("step_noop.npz")
+    n = g["board_in"].shape[0]
+    bo, so, ro, fo = oracle.step_batch(g["board_in"], g["action"], g["score_in"].astype(np.uint32), seed=1, step_index=0, opts=2)
+    assert np.array_equal(bo, g["board_out"]) and np.array_equal(so.astype(np.int32), g["score_out"])
+    assert np.array_equal(ro, g["reward"], equal_nan=True)
+    assert np.array_equal(fo & 1, g["done"]) and not ((fo >> 1) & 1).any() and int(g["done"].sum()) >= 20
