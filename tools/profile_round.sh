@@ -13,8 +13,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_r02_f
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_r02_write -- $B --no-graph --no-beam --no-rollout --no-extra > /dev/null 2> $OUT/prof_r02_write.err
 echo "write done"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/prof_r02_sq -- $B --no-graph --no-extra > /dev/null 2> $OUT/prof_r02_sq.err
+# (no graph-captured leg in a counter pass: the rollout collector's hipGraph capture hung under --pmc)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/prof_r02_sq -- $B --no-graph --no-extra --no-rollout > /dev/null 2> $OUT/prof_r02_sq.err
 echo "sq done"
 cd $ROOT
 for d in kt fetch write sq; do python3 tools/prof_summary.py $OUT/prof_r02_$d > $OUT/prof_r02_$d.summary.txt 2>&1; done
-head -c 600 $OUT/prof_r02_kt.json; echo
+head -c 300 $OUT/prof_r02_kt.json; echo
