@@ -463,7 +463,10 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     uint4 *out = static_cast<uint4 *>(boards_out);
     const bool f64 = opts & G2048_STEP_REWARD_F64, ar = opts & G2048_STEP_AUTO_RESET;
     const unsigned tune = (opts >> G2048_STEP_TUNE_SHIFT) & 3u;            // 0 = default
-    const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : kStepBoardsPerLane;
+    // default: one board per lane -- measured fastest up to a few Mi boards per launch, where the launch is short and
+    // wave-level parallelism hides the load latency; from 4 Mi boards on (beyond the Infinity Cache) two boards per lane,
+    // both loads in flight before the first is computed, stream 4-5 % faster (profiles/r02_step_tune.txt)
+    const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : (n >= ((size_t)1 << 22) ? 2 : kStepBoardsPerLane);
 #define G2048_LAUNCH_STEP(F, A, BB) \
     hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, in, actions, out, \
                        score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)

@@ -373,11 +373,12 @@ def main():
                 ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
         big_steps()
         gb, ab, bb2 = (None, None, None) if args.no_graph else graph_of(big_steps, dev)
-        ms = timed_replay(gb, ab, bb2, big_steps, reps=2)
+        ms = timed_replay(gb, ab, bb2, big_steps, reps=4)
         us = ms * 1e3 / KB
         result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
                                            "kernel_us": us, "boards_per_launch": nb,
+                                           "kernel": "step_kernel<false,false,2,256> (two boards per lane from 4 Mi boards per launch on)",
                                            "algorithmic_bytes_per_launch": nb * STEP_BYTES_F32,
                                            "board_steps_per_s": nb / us * 1e6,
                                            "note": "16,777,216 boards per launch: 738 MB of streams, beyond the 256 MiB "
