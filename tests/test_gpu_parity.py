@@ -88,6 +88,22 @@ def test_step_vs_oracle_sizes(ops, oracle, n):
         assert set(np.unique(host(a))) == {0, 1, 2, 3}
 
 
+def test_prepared_step_equals_step(ops):
+    """ops.PreparedStep (arguments bound and checked once, then one ctypes call per launch) == ops.step."""
+    n = 70000
+    b = ops.synth_boards(n, seed=SEED + 5, device=DEV)
+    a = ops.synth_actions(n, seed=SEED + 5, step_index=0, device=DEV)
+    s1 = torch.zeros(n, dtype=torch.int32, device=DEV); s2 = torch.zeros_like(s1)
+    o2 = torch.empty_like(b); r2 = torch.empty(n, dtype=torch.float32, device=DEV); f2 = torch.empty(n, dtype=torch.uint8, device=DEV)
+    call = ops.PreparedStep(b, a, s2, SEED, 3, out=o2, reward=r2, flags=f2)
+    s2.zero_()
+    for t in (4, 5, 6):
+        o1, r1, f1 = ops.step(b, a, s1, SEED, t, 3)
+        call(t)
+        assert bool((o1 == o2).all()) and bool((f1 == f2).all()) and bool((s1 == s2).all())
+        assert np.array_equal(host(r1).view(np.uint32), host(r2).view(np.uint32))
+
+
 def test_step_select_direction_variant(ops, oracle):
     """tune bit 2: the round-1 direction handling (per-lane selects), kept for A/B -- same results as the selector table."""
     n = 300001
