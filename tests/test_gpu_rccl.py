@@ -62,8 +62,15 @@ CHILD = textwrap.dedent("""
 """) % (REPO, PKG)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_rccl_process_group_collectives_and_graph_capture(tmp_path):
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531",
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), G2048_DIST_FORCE="1")
     script = tmp_path / "rccl_child.py"
     script.write_text(CHILD)
