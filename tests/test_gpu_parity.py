@@ -288,6 +288,13 @@ def test_empty_batches_are_noops(ops):
     a, p = ops.beam_get_action(e, 20, 30)
     assert a.numel() == 0 and p.numel() == 0
     assert int(ops.metrics(e).sum()) == 0
+    # round-2 entry points
+    succ, r, d, c = ops.simulate_move_sampled(e, z8)
+    assert succ.shape == (0, 8, 16) and c.numel() == 0
+    o, act, pr, rw2, fl2 = ops.rollout_step(e, torch.empty((0, 4), dtype=torch.float32, device=DEV), z32, 1, 0)
+    assert o.shape == (0, 16) and act.numel() == 0
+    seen = ops.SeenStates(DEV, capacity_log2=4)
+    assert ops.remember_shaping(seen, e, z8, z8, torch.empty(0, dtype=torch.float64, device=DEV)).numel() == 0 and seen.index == 0
 
 
 def test_config5_total_on_one_gpu_properties(ops):
