@@ -355,11 +355,19 @@ G2048_HD uint32_t spawn_prefix(Board &b, uint32_t h, bool enable = true, uint32_
 }
 
 // reset (environment/game_2048.py:29-48): empty board, two spawns
+// The two spawns start from a known board, so no empty-cell ranking is needed: the first draw indexes 16 cells directly
+// (((h >> 16) * 16) >> 16 = h >> 28), the second indexes the 15 that are left, i.e. skips the first one's cell.
 G2048_HD Board fresh_board(uint32_t h0, uint32_t h1)
 {
-    Board b = {{0u, 0u, 0u, 0u}};
-    spawn(b, h0);
-    spawn(b, h1);
+    const uint32_t cell0 = h0 >> 28;
+    uint32_t cell1 = ((h1 >> 16) * 15u) >> 16;
+    cell1 += cell1 >= cell0 ? 1u : 0u;
+    const uint32_t code0 = (h0 & 0xffffu) >= 58982u ? 2u : 1u, code1 = (h1 & 0xffffu) >= 58982u ? 2u : 1u;
+    const uint32_t t0 = code0 << (8u * (cell0 & 3u)), t1 = code1 << (8u * (cell1 & 3u));
+    const uint32_t r0 = cell0 >> 2, r1 = cell1 >> 2;
+    Board b;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) b.w[r] = (r0 == r ? t0 : 0u) | (r1 == r ? t1 : 0u);
     return b;
 }
 
