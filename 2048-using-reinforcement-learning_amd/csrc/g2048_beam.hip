@@ -8,6 +8,9 @@
 // runs it once per game (g2048_beam_get_action), play_kernel loops it with the env step (g2048_play_games).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
 
 #include "../../include/g2048.h"
 #include "g2048_board.h"
@@ -244,6 +247,43 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
 // is reached, with the per-move bookkeeping (milestones, valid / invalid counters) in registers. No launch, no host,
 // no other game is involved between two moves; draws are the ones the step-by-step driver uses -- move t of game g
 // takes (seed, BEAM, t, g, j) for the search and (seed, STEP, t, g) for the spawn -- so the results are identical.
+// Per-game bookkeeping of the evaluation loop (evaluate_beam_search.py:48-69), identical in every lane.
+struct GameState {
+    Board b;
+    uint32_t sc;
+    int32_t ms[8];
+    int32_t nvalid, ninvalid, t;
+    unsigned long long expanded;
+    bool alive;
+};
+
+__device__ __forceinline__ void game_apply(GameState &st, const StepOut &o, uint32_t expanded)
+{
+    st.b = o.board;
+    st.sc += o.gain;
+    st.expanded += expanded;
+    const int32_t maxcode = (int32_t)(o.flags >> G2048_FLAG_MAXCODE_SHIFT);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (st.ms[k] < 0 && maxcode >= 6 + k) st.ms[k] = st.t;     // evaluate_beam_search.py:60-64
+    if (o.flags & G2048_FLAG_VALID) ++st.nvalid; else ++st.ninvalid;
+    st.alive = !(o.flags & G2048_FLAG_DONE);
+    ++st.t;
+}
+
+__device__ __forceinline__ void game_store(const GameState &st, size_t g, uint4 *boards, uint32_t *score, int32_t *moves_out,
+                                           int32_t *valid_out, int32_t *invalid_out, int4 *milestone_out,
+                                           unsigned long long *expanded_out, uint8_t *alive_out)
+{
+    boards[g] = make_uint4(st.b.w[0], st.b.w[1], st.b.w[2], st.b.w[3]);
+    score[g] = st.sc;
+    moves_out[g] = st.t; valid_out[g] = st.nvalid; invalid_out[g] = st.ninvalid;
+    milestone_out[2 * g] = make_int4(st.ms[0], st.ms[1], st.ms[2], st.ms[3]);
+    milestone_out[2 * g + 1] = make_int4(st.ms[4], st.ms[5], st.ms[6], st.ms[7]);
+    if (expanded_out) expanded_out[g] = st.expanded;
+    alive_out[g] = st.alive ? 1 : 0;
+}
+
+// One wavefront plays one game from start to finish.
 template <int PASSES>
 __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
                                                  int32_t *__restrict__ moves_out, int32_t *__restrict__ valid_out,
@@ -256,33 +296,186 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
     const uint4 rv = boards[g];
-    Board b = {{rv.x, rv.y, rv.z, rv.w}};
-    uint32_t sc = score[g];
-    int32_t ms[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    int32_t nvalid = 0, ninvalid = 0, t = 0;
-    unsigned long long expanded = 0ull;
-    bool alive = true;
-    for (; t < max_moves && alive; ++t) {
-        const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)t), ks = rng_keys(seed, DOM_STEP, (uint64_t)t);
-        const Decision d = beam_decide<PASSES>(sh, b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
-        const StepOut o = step_board(b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u));
-        b = o.board;
-        sc += o.gain;
-        expanded += d.expanded;
-        const int32_t maxcode = (int32_t)(o.flags >> G2048_FLAG_MAXCODE_SHIFT);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (ms[k] < 0 && maxcode >= 6 + k) ms[k] = t;          // evaluate_beam_search.py:60-64
-        if (o.flags & G2048_FLAG_VALID) ++nvalid; else ++ninvalid;
-        alive = !(o.flags & G2048_FLAG_DONE);
+    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    while (st.t < max_moves && st.alive) {
+        const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t), ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
+        const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
+        game_apply(st, step_board(st.b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u)), d.expanded);
     }
-    if (threadIdx.x == 0) {
-        boards[g] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
-        score[g] = sc;
-        moves_out[g] = t; valid_out[g] = nvalid; invalid_out[g] = ninvalid;
-        milestone_out[2 * g] = make_int4(ms[0], ms[1], ms[2], ms[3]);
-        milestone_out[2 * g + 1] = make_int4(ms[4], ms[5], ms[6], ms[7]);
-        if (expanded_out) expanded_out[g] = expanded;
-        alive_out[g] = alive ? 1 : 0;
+    if (threadIdx.x == 0) game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
+}
+
+// ---------------------------------------------------------------- speculative helpers
+// A game is a chain of decisions, ~80 us each on a lone wavefront, and the evaluation ends with a long tail of few games
+// (the ones the reference's DOWN quirk keeps stuck until the move cap, and the long good ones) on an almost idle chip.
+// The env's draws are counter-based, so the owner of a game knows, before it searches move t, every board move t + 1
+// can start from: the successor of each valid action (with the spawn of move t) or, after an invalid move, the same
+// board again -- and then again at t + 2, ... The same launch therefore carries helper wavefronts (the blocks after the
+// last game; they are dispatched last, i.e. when games have ended and SIMDs are free). A game whose owner has registered
+// it gets kSpec request slots, each served by one helper: the owner posts (root, move index) pairs, searches move t
+// itself, steps, and if the board it now has is one it posted for t + 1 it takes that helper's decision instead of
+// searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
+// would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
+// Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
+constexpr int kSpec = 4;
+constexpr size_t kSpecMaxGames = 1u << 16;           // beyond this the workspace is not worth it: one wavefront per game
+constexpr uint32_t kNone = 0xffffffffu;
+
+struct SpecSlot {                 // 64 bytes per (game, slot), in the workspace g2048_play_games allocates
+    uint32_t board[4], t;         // request: search this root with the draws of move t ...
+    uint32_t seq;                 // ... request number (the owner's round), stored last (release); kNone: the game is over
+    uint32_t bound;               // a helper serves this slot
+    uint32_t res_action, res_expanded;
+    uint32_t res_seq;             // stored last by the helper: the result answers request res_seq
+    uint32_t pad[6];
+};
+struct SpecCtl { uint32_t resolved, registered, next_unit, pad; };
+
+__device__ __forceinline__ uint32_t ld_acquire(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_release(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <int PASSES>
+__device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t *reg_list, SpecSlot *slots, uint32_t n_games,
+                            int width, int depth, uint32_t early_thr, uint32_t mid_thr, uint64_t seed, uint64_t id_base,
+                            bool fixed_down)
+{
+    for (;;) {
+        uint32_t u = 0;
+        if (threadIdx.x == 0) u = atomicAdd(&ctl->next_unit, 1u);
+        u = uniform(u);
+        const uint32_t ticket = u / kSpec, k = u % kSpec;
+        if (ticket >= n_games) return;
+        uint32_t g;
+        for (;;) {                                                   // until the ticket's game exists, or no game is left
+            g = uniform(ld_acquire(&reg_list[ticket]));
+            if (g != kNone) break;
+            if (uniform(ld_relaxed(&ctl->resolved)) >= n_games) return;
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        SpecSlot *slot = slots + (size_t)g * kSpec + k;
+        if (threadIdx.x == 0) st_relaxed(&slot->bound, 1u);
+        uint32_t last = 0u;
+        for (;;) {
+            const uint32_t q = uniform(ld_acquire(&slot->seq));
+            if (q == kNone) break;                                   // every owner closes its slots when its game ends
+            if (q == last) { __builtin_amdgcn_s_sleep(16); continue; }
+            const Board root = {{uniform(ld_relaxed(&slot->board[0])), uniform(ld_relaxed(&slot->board[1])),
+                                 uniform(ld_relaxed(&slot->board[2])), uniform(ld_relaxed(&slot->board[3]))}};
+            const uint32_t t = uniform(ld_relaxed(&slot->t));
+            // (a payload torn by the owner moving on carries the old q, which the owner no longer accepts)
+            const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)t);
+            const Decision d = beam_decide<PASSES>(sh, root, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, id_base + g,
+                                                   fixed_down);
+            if (threadIdx.x == 0) {
+                st_relaxed(&slot->res_action, d.action);
+                st_relaxed(&slot->res_expanded, d.expanded);
+                st_release(&slot->res_seq, q);
+            }
+            last = q;
+        }
+    }
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
+                                                      int32_t *__restrict__ moves_out, int32_t *__restrict__ valid_out,
+                                                      int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
+                                                      unsigned long long *__restrict__ expanded_out,
+                                                      uint8_t *__restrict__ alive_out, int width, int depth, uint32_t early_thr,
+                                                      uint32_t mid_thr, int max_moves, uint64_t seed, uint64_t id_base,
+                                                      bool fixed_down, SpecCtl *ctl, uint32_t *reg_list, SpecSlot *slots,
+                                                      uint32_t n_games, int stuck_thr, uint32_t reg_resolved, uint32_t wait_ticks)
+{
+    __shared__ BeamShared<PASSES> sh;
+    __shared__ uint4 s_req_board[kSpec];
+    __shared__ uint32_t s_req_t[kSpec];
+    if (blockIdx.x >= n_games) {
+        spec_helper<PASSES>(sh, ctl, reg_list, slots, n_games, width, depth, early_thr, mid_thr, seed, id_base, fixed_down);
+        return;
+    }
+    const uint32_t lane = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const uint64_t gid = id_base + g;
+    const uint4 rv = boards[g];
+    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    SpecSlot *const my = slots + g * kSpec;
+    bool registered = false;
+    uint32_t seq = 0u;
+    int stuck = 0;                                                   // invalid moves minus valid ones, floored at 0
+    while (st.t < max_moves && st.alive) {
+        if (!registered && (stuck >= stuck_thr || ((st.t & 31) == 0 && uniform(ld_relaxed(&ctl->resolved)) >= reg_resolved))) {
+            if (lane == 0) st_release(&reg_list[atomicAdd(&ctl->registered, 1u)], (uint32_t)g);
+            registered = true;
+        }
+        const Keys ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
+        const uint32_t draw = rng_draw(ks.k0, ks.k1, gid, 0u);
+        uint32_t on = 0u;                                            // slots that hold a request of this round
+        if (registered) {
+            const uint32_t bound = (uint32_t)__ballot(lane < (uint32_t)kSpec && ld_relaxed(&my[lane & (kSpec - 1)].bound) != 0u);
+            if (bound) {
+                ++seq;
+                // lanes 0..3: the env's successor of action `lane`; the valid ones that do not end the game come first,
+                // then, if some action is invalid, the unchanged board at t + 1, t + 2, ...
+                const StepOut c = step_board(st.b, lane & 3u, draw);
+                const bool cv = lane < 4u && (c.flags & G2048_FLAG_VALID) && !(c.flags & G2048_FLAG_DONE);
+                const unsigned long long vb = __ballot(cv);
+                const uint32_t nv = (uint32_t)__popcll(vb), r = prefix_count(vb);
+                const bool any_invalid = (uint32_t)__popcll(__ballot(lane < 4u && !(c.flags & G2048_FLAG_VALID))) != 0u;
+                if (cv && r < (uint32_t)kSpec) {
+                    s_req_board[r] = make_uint4(c.board.w[0], c.board.w[1], c.board.w[2], c.board.w[3]);
+                    s_req_t[r] = (uint32_t)st.t + 1u;
+                }
+                if (lane >= nv && lane < (uint32_t)kSpec) {
+                    s_req_board[lane] = make_uint4(st.b.w[0], st.b.w[1], st.b.w[2], st.b.w[3]);
+                    s_req_t[lane] = any_invalid ? (uint32_t)st.t + 1u + (lane - nv) : kNone;
+                }
+                __syncthreads();
+                const bool post = lane < (uint32_t)kSpec && ((bound >> lane) & 1u) && s_req_t[lane & (kSpec - 1)] < (uint32_t)max_moves;
+                if (post) {
+                    const uint4 q = s_req_board[lane];
+                    SpecSlot *sl = my + lane;
+                    st_relaxed(&sl->board[0], q.x); st_relaxed(&sl->board[1], q.y);
+                    st_relaxed(&sl->board[2], q.z); st_relaxed(&sl->board[3], q.w);
+                    st_relaxed(&sl->t, s_req_t[lane]);
+                    st_release(&sl->seq, seq);
+                }
+                on = (uint32_t)__ballot(post);
+            }
+        }
+        {
+            const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t);
+            const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
+            const StepOut o = step_board(st.b, d.action, draw);
+            game_apply(st, o, d.expanded);
+            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+        }
+        while (on && st.alive && st.t < max_moves) {                 // decisions the helpers have made for where we are now
+            const uint4 q = s_req_board[lane & (kSpec - 1)];
+            const bool hit = lane < (uint32_t)kSpec && ((on >> lane) & 1u) && s_req_t[lane & (kSpec - 1)] == (uint32_t)st.t &&
+                             q.x == st.b.w[0] && q.y == st.b.w[1] && q.z == st.b.w[2] && q.w == st.b.w[3];
+            const unsigned long long hb = __ballot(hit);
+            if (!hb) break;
+            const uint32_t k = (uint32_t)__builtin_ctzll(hb);
+            const unsigned long long t0 = wall_clock64();
+            bool ready;
+            while (!(ready = uniform(ld_acquire(&my[k].res_seq)) == seq) && wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
+            if (!ready) break;                                       // a late helper: search this move ourselves
+            const uint32_t action = uniform(ld_relaxed(&my[k].res_action)), ex = uniform(ld_relaxed(&my[k].res_expanded));
+            const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
+            const StepOut o = step_board(st.b, action, rng_draw(k2.k0, k2.k1, gid, 0u));
+            game_apply(st, o, ex);
+            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+            on &= ~(1u << k);
+        }
+        __syncthreads();                                             // s_req_* are rewritten next round
+    }
+    if (lane < (uint32_t)kSpec) st_release(&my[lane].seq, kNone);
+    if (lane == 0) {
+        game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
+        atomicAdd(&ctl->resolved, 1u);
     }
 }
 
@@ -339,20 +532,64 @@ int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         g2048_set_last_error_("g2048_play_games: board / milestone arrays must be 16-byte aligned"); return G2048_ERR_ARG;
     }
     if (width < 1 || width > kMaxWidth || max_moves < 0 || early_threshold < 0 || mid_threshold < 0 || n_games > 0x7fffffffu ||
-        (opts & ~G2048_BEAM_FIXED_DOWN)) {
+        (opts & ~(G2048_BEAM_FIXED_DOWN | G2048_PLAY_ONE_PHASE))) {
         g2048_set_last_error_("g2048_play_games: bad width / max_moves / thresholds / opts / n_games"); return G2048_ERR_ARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)n_games);
     const bool fd = (opts & G2048_BEAM_FIXED_DOWN) != 0;
-#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_kernel<P>, grid, dim3(64), 0, s, static_cast<uint4 *>(boards_inout), score_inout, moves_out, \
-                           valid_out, invalid_out, reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, \
-                           width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd)
-    if (width <= 16) G2048_LAUNCH_PLAY(1);
-    else if (width <= 32) G2048_LAUNCH_PLAY(2);
-    else if (width <= 64) G2048_LAUNCH_PLAY(4);
-    else G2048_LAUNCH_PLAY(8);
+    const int passes = width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8;
+#define G2048_PLAY_ARGS static_cast<uint4 *>(boards_inout), score_inout, moves_out, valid_out, invalid_out, \
+                        reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, width, depth, \
+                        (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd
+    if ((opts & G2048_PLAY_ONE_PHASE) || n_games > kSpecMaxGames) {
+        const dim3 grid((unsigned)n_games);
+#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS)
+        if (passes == 1) G2048_LAUNCH_PLAY(1);
+        else if (passes == 2) G2048_LAUNCH_PLAY(2);
+        else if (passes == 4) G2048_LAUNCH_PLAY(4);
+        else G2048_LAUNCH_PLAY(8);
 #undef G2048_LAUNCH_PLAY
+    } else {
+        // Helpers: four per game for a small batch, a quarter of the games for a large one, never more than 2048 wavefronts
+        // (a quarter of the chip's wave slots, so owners always find room whatever the dispatch order). A game registers
+        // for them once it is stuck (16 more invalid than valid moves lately) or once an eighth of the games (at least 256)
+        // is left; an owner polls at most 60 us for a posted result. Measured flat around these values
+        // (profiles/r02_eval_helpers.txt); G2048_PLAY_TUNE = "helpers,games_left,stuck,wait_us" overrides them for
+        // measurements.
+        const uint32_t n = (uint32_t)n_games;
+        uint32_t helpers = std::min<uint32_t>(std::min<uint32_t>((uint32_t)kSpec * n, std::max<uint32_t>(n / 4u, 1024u)), 2048u);
+        uint32_t games_left = std::max<uint32_t>(n / 8u, 256u);
+        int stuck_thr = 16;
+        uint32_t wait_us = 60;
+        if (const char *tune = getenv("G2048_PLAY_TUNE")) {
+            unsigned h = helpers, l = games_left, w = wait_us; int st = stuck_thr;
+            if (sscanf(tune, "%u,%u,%d,%u", &h, &l, &st, &w) >= 1) {
+                helpers = std::min<uint32_t>(std::min<uint32_t>(h, (uint32_t)kSpec * n), 2048u);
+                games_left = l; stuck_thr = st; wait_us = std::min<uint32_t>(w, 1000u);
+            }
+        }
+        const uint32_t reg_resolved = games_left >= n ? 0u : n - games_left;
+        const size_t list_bytes = (n_games * sizeof(uint32_t) + 63u) & ~(size_t)63u;
+        const size_t bytes = 64u + list_bytes + n_games * kSpec * sizeof(SpecSlot);
+        char *ws = nullptr;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, s);
+        if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+        SpecCtl *ctl = reinterpret_cast<SpecCtl *>(ws);
+        uint32_t *reg_list = reinterpret_cast<uint32_t *>(ws + 64);
+        SpecSlot *slots = reinterpret_cast<SpecSlot *>(ws + 64 + list_bytes);
+        (void)hipMemsetAsync(ws, 0, bytes, s);
+        (void)hipMemsetAsync(reg_list, 0xff, list_bytes, s);
+        const dim3 grid((unsigned)(n + helpers));
+#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
+                                                stuck_thr, reg_resolved, wait_us * 100u)
+        if (passes == 1) G2048_LAUNCH_PLAY(1);
+        else if (passes == 2) G2048_LAUNCH_PLAY(2);
+        else if (passes == 4) G2048_LAUNCH_PLAY(4);
+        else G2048_LAUNCH_PLAY(8);
+#undef G2048_LAUNCH_PLAY
+        (void)hipFreeAsync(ws, s);
+    }
+#undef G2048_PLAY_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;

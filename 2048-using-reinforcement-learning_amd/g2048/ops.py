@@ -459,10 +459,13 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
 
 
 def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512, mid_threshold=1024, seed=0x2048,
-               game_id_base=0, fixed_down=False):
+               game_id_base=0, fixed_down=False, one_phase=False):
     """Every game played to completion in ONE launch (beam get_action -> env step fused per game, reference
-    run_evaluation.py:48-69). boards / scores are updated in place. Returns a dict of per-game tensors:
-    moves, valid_moves, invalid_moves (int32), milestone_move (int32 (n,8), -1 = never), expanded (int64), alive (uint8)."""
+    run_evaluation.py:48-69): one wavefront owns a game; helper wavefronts of the same launch search the boards the next
+    moves can start from ahead of time, for the games that are left when the chip empties (g2048_beam.hip;
+    one_phase=True plays without them -- the games are identical). boards / scores are updated in place. Returns a dict
+    of per-game tensors: moves, valid_moves, invalid_moves (int32), milestone_move (int32 (n,8), -1 = never), expanded
+    (int64), alive (uint8)."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     _require_scores(scores)
     n = boards.shape[0]
@@ -478,7 +481,8 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
     L.call(dev, L.lib().g2048_play_games, boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
            out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
            out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
-           int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0,
+           int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
+           (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0),
            L.stream_ptr(dev))
     return out
 

@@ -82,6 +82,10 @@ enum {
 /* opts of g2048_beam_get_action */
 #define G2048_BEAM_FIXED_DOWN  0x01u   /* use the true DOWN move instead of the reference's rot180 quirk (not parity) */
 
+/* further opts of g2048_play_games */
+#define G2048_PLAY_ONE_PHASE   0x02u   /* every game on its one wavefront only, no speculative helper wavefronts; the games
+                                          are the same either way -- an A/B switch for tests and measurements */
+
 #define G2048_BEAM_MAX_WIDTH   128
 
 const char *g2048_last_error(void);

@@ -154,3 +154,42 @@ def test_fused_play_games_equals_stepwise_drivers(g2048):
                   "total_expansions", "unfinished"):
             assert r0[k] == r1[k], (w, k)
         assert np.array_equal(r0["final_boards"], r1["final_boards"])
+
+
+PLAY_KEYS = ("scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games",
+             "total_expansions", "unfinished")
+
+
+@pytest.mark.parametrize("n,w,d,cap,fixed_down", [
+    (1, 20, 12, 900, False),        # one game: four helpers from the first move
+    (37, 8, 6, 900, False),         # one 64-child pass per level
+    (300, 20, 10, 1500, False),     # two passes; 300 > 256 so the late registration path (few games left) runs too
+    (24, 40, 4, 400, False),        # four passes
+    (6, 100, 3, 150, False),        # eight passes
+    (64, 20, 8, 700, True),         # true DOWN: no stuck games, the helpers serve valid-move successors only
+])
+def test_speculative_helpers_play_the_same_games(g2048, n, w, d, cap, fixed_down):
+    """g2048_play_games with helper wavefronts (decisions for the next moves' possible roots searched ahead of time)
+    == every game on its one wavefront (G2048_PLAY_ONE_PHASE): helpers may only change the time."""
+    kw = dict(num_games=n, beam_width=w, search_depth=d, seed=4242 + n, max_moves=cap, game_id_base=(1 << 33) + 9,
+              fixed_down=fixed_down)
+    r0 = g2048.evaluate_beam_search(one_phase=True, **kw)
+    for rep in range(2):                                   # helper timing differs run to run, the games may not
+        r1 = g2048.evaluate_beam_search(**kw)
+        for k in PLAY_KEYS:
+            assert r0[k] == r1[k], (k, rep)
+        assert np.array_equal(r0["final_boards"], r1["final_boards"])
+    if not fixed_down and n >= 37:
+        assert sum(r0["invalid_moves"]) > 0                # the repeated-root chain was exercised
+
+
+def test_speculative_helpers_tuning_extremes(g2048, monkeypatch):
+    """No helper at all, helpers that are always late (0 us wait) and eager registration give the same games."""
+    kw = dict(num_games=96, beam_width=12, search_depth=8, seed=99, max_moves=1200)
+    r0 = g2048.evaluate_beam_search(one_phase=True, **kw)
+    for tune in ("0,256,16,60", "384,256,16,0", "64,1000000,1,200", "2048,0,1000000,60"):
+        monkeypatch.setenv("G2048_PLAY_TUNE", tune)
+        r1 = g2048.evaluate_beam_search(**kw)
+        for k in PLAY_KEYS:
+            assert r0[k] == r1[k], (tune, k)
+        assert np.array_equal(r0["final_boards"], r1["final_boards"])
