@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
 // would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
 // Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
-constexpr int kSpec = 4;
+constexpr int kSpec = 8;
 constexpr size_t kSpecMaxGames = 1u << 16;           // beyond this the workspace is not worth it: one wavefront per game
 constexpr uint32_t kNone = 0xffffffffu;
 

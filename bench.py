@@ -433,9 +433,14 @@ def main():
         from g2048 import evaluate_beam_search
         evaluate_beam_search(256, BEAM_WIDTH, BEAM_DEPTH, seed=1, max_moves=50, device=dev)      # warm
         ev = evaluate_beam_search(BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
+        ev1 = evaluate_beam_search(BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev, one_phase=True)
+        ev100 = evaluate_beam_search(100, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
         sm = ev["summary"]
         result["evaluation"] = {"metric": "4096 complete beam-search games (width 20, depth 30, 5000-move cap), one launch",
-                                "seconds": ev["elapsed_s"], "moves": ev["total_moves"], "moves_per_s": sm["moves_per_s"],
+                                "seconds": ev["elapsed_s"], "seconds_without_helper_wavefronts": ev1["elapsed_s"],
+                                "same_games_without_helpers": ev["scores"] == ev1["scores"] and ev["moves"] == ev1["moves"],
+                                "seconds_100_games": ev100["elapsed_s"],
+                                "moves": ev["total_moves"], "moves_per_s": sm["moves_per_s"],
                                 "expansions_per_s": sm["expansions_per_s"], "rate_2048_or_more": sm["rate_2048_or_more"],
                                 "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
                                                                                                 "average_score": 18945.6}}

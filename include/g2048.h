@@ -171,7 +171,10 @@ int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void
  * (one wavefront) alternates BeamSearchAgent.get_action (no caller mask) and Game2048Env.step from boards_inout /
  * score_inout until it is over or max_moves is reached, entirely on the device. Move t of game g uses the draws of
  * g2048_beam_get_action(step_index = t, game id g) and g2048_step(step_index = t, board id g), so the outcome equals
- * the step-by-step loop. Outputs per game: final board / score (in place), moves played, valid / invalid move counts,
+ * the step-by-step loop. Unless opts has G2048_PLAY_ONE_PHASE (or n_games > 65,536) the launch also carries helper
+ * wavefronts that search the roots a game's next moves can start from ahead of time (same decisions, less latency for the
+ * last games; workspace from hipMallocAsync on `stream`, freed in stream order).
+ * Outputs per game: final board / score (in place), moves played, valid / invalid move counts,
  * milestone_move_out[g][0..8) = move at which tiles 64..8192 first appeared (-1 = never), total children expanded
  * (optional), alive_out[g] = 1 if the game hit max_moves without finishing. */
 int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
