@@ -76,6 +76,14 @@ def all_gather_scores(scores):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
 
 
+def all_gather_rows(rows):
+    """Row-wise concatenation of every rank's (n_r, C) int64 table in rank order (ragged n_r allowed)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
+        return rows.clone()
+    flat = all_gather_scores(rows.reshape(-1))
+    return flat.reshape(-1, rows.shape[1])
+
+
 def reduce_metrics(metrics):
     """Sum of the per-shard metric vectors (g2048_metrics layout) over all ranks, in place."""
     if dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):

@@ -29,7 +29,7 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_se
 
 def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
                          device="cuda", game_id_base=0, check_every=64, early_game_threshold=512,
-                         mid_game_threshold=1024, fixed_down=False, use_graph=True, fused=True, one_phase=False):
+                         mid_game_threshold=1024, fixed_down=False, use_graph=True, fused=True, one_phase=False, _table_only=False):
     """fused=True (default): every game is played start to finish by its own wavefront in one kernel launch
     (`g2048_play_games`; helper wavefronts of that launch pre-compute decisions for the last games, one_phase=True turns
     them off -- same games). fused=False: the step-by-step loop (one beam launch + one step launch + bookkeeping per move for
@@ -106,33 +106,68 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t_start
 
-    scores = env.scores.cpu().numpy().astype("int64")
-    final_boards = ops.unpack(env.boards).cpu().numpy().reshape(n, 4, 4)
-    highest = final_boards.reshape(n, 16).max(axis=1)
-    ms_host = ms_move.cpu().numpy()
+    # one int64 row per game: score, moves, valid, invalid, alive, expanded, 8 milestone moves, 16 tiles
+    table = torch.cat([env.scores.to(torch.int64)[:, None], moves.to(torch.int64)[:, None], valid_cnt.to(torch.int64)[:, None],
+                       invalid_cnt.to(torch.int64)[:, None], alive.to(torch.int64)[:, None], expanded_sum[:, None],
+                       ms_move.to(torch.int64), ops.unpack(env.boards).to(torch.int64).reshape(n, 16)], dim=1)
+    if _table_only:
+        return table.cpu().numpy()
+    return results_from_table(table.cpu().numpy(), elapsed, beam_width, search_depth, seed, max_moves)
+
+
+TABLE_COLUMNS = 6 + len(MILESTONES) + 16
+
+
+def results_from_table(table, elapsed, beam_width, search_depth, seed, max_moves):
+    """The result dict from the per-game table (rows in global game order; columns as built in evaluate_beam_search)."""
+    n = table.shape[0]
+    scores = table[:, 0]
+    final_boards = table[:, 14:30].reshape(n, 4, 4).astype("int32")
+    highest = final_boards.reshape(n, 16).max(axis=1) if n else table[:, 0]
+    ms_host = table[:, 6:14]
     order = sorted(range(n), key=lambda i: scores[i], reverse=True)       # stable, like the reference's top-5 update
     best = int(order[0]) if n else 0
     results = {
         "scores": [int(s) for s in scores],
         "highest_tiles": [int(h) for h in highest],
-        "moves": [int(m) for m in moves.cpu().numpy()],
-        "valid_moves": [int(m) for m in valid_cnt.cpu().numpy()],
-        "invalid_moves": [int(m) for m in invalid_cnt.cpu().numpy()],
+        "moves": [int(m) for m in table[:, 1]],
+        "valid_moves": [int(m) for m in table[:, 2]],
+        "invalid_moves": [int(m) for m in table[:, 3]],
         "milestones": {m: [int(v) for v in ms_host[:, k] if v >= 0] for k, m in enumerate(MILESTONES)},
         "best_games": [int(i) for i in order[:5]],
         "final_boards": final_boards,
         "best_board": final_boards[best].copy() if n else None,
         "best_score": int(scores[best]) if n else 0,
         "best_game_idx": best,
-        "unfinished": int(alive.sum().item()),
-        "total_moves": int(moves.sum().item()),
-        "total_expansions": int(expanded_total.item()),
+        "unfinished": int(table[:, 4].sum()),
+        "total_moves": int(table[:, 1].sum()),
+        "total_expansions": int(table[:, 5].sum()),
         "elapsed_s": elapsed,
         "parameters": {"beam_width": beam_width, "search_depth": search_depth, "num_games": n, "seed": seed,
                        "max_moves": max_moves},
     }
     results["summary"] = summarize(results)
     return results
+
+
+def evaluate_beam_search_sharded(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000, device=None,
+                                 game_id_base=0, **kw):
+    """The evaluation over all ranks of the default process group (one process per GPU, torchrun environment): games are
+    independent and every draw is keyed by the global game id, so rank r plays the contiguous range g2048.dist.shard gives
+    it with no communication, and one all-gather of the per-game table (30 int64 per game) at the end gives every rank the
+    result of the whole evaluation -- identical to evaluate_beam_search(num_games) on one GPU. elapsed_s = slowest rank."""
+    from . import dist as gdist
+    w, r, lr = gdist.world()
+    dev = torch.device(device) if device is not None else torch.device("cuda", lr)
+    lo, hi = gdist.shard(num_games, r, w)
+    t0 = time.perf_counter()
+    part = evaluate_beam_search(hi - lo, beam_width, search_depth, seed=seed, max_moves=max_moves, device=dev,
+                                game_id_base=game_id_base + lo, _table_only=True, **kw)
+    table = gdist.all_gather_rows(torch.from_numpy(part).to(dev))
+    elapsed = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+    res = results_from_table(table.cpu().numpy(), elapsed, beam_width, search_depth, seed, max_moves)
+    res["parameters"]["world_size"] = w
+    return res
 
 
 def summarize(results):

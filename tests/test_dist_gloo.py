@@ -76,3 +76,59 @@ def test_shard_ranges_cover_exactly():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1
+
+
+def _rows_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2048 import dist as gdist
+    from g2048.evaluate import TABLE_COLUMNS
+    gdist.init("gloo")
+    lo, hi = gdist.shard(37, rank, world)                       # ragged: 19 + 18 games
+    full = np.random.default_rng(5).integers(0, 1 << 40, size=(37, TABLE_COLUMNS), dtype=np.int64)
+    got = gdist.all_gather_rows(torch.from_numpy(full[lo:hi].copy()))
+    gdist.barrier()
+    if rank == 0:
+        q.put((got.numpy(), full))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_evaluation_table_gather():
+    """The evaluation's end-of-run exchange (evaluate_beam_search_sharded): ragged per-rank tables come back in global
+    game order on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got, full)
+
+
+def test_results_from_table_is_the_single_process_result():
+    """results_from_table over concatenated shard tables == over the whole table (the merge is a concatenation)."""
+    sys.path.insert(0, PKG)
+    from g2048.evaluate import results_from_table, TABLE_COLUMNS, MILESTONES
+    rng = np.random.default_rng(11)
+    n = 23
+    t = np.zeros((n, TABLE_COLUMNS), dtype=np.int64)
+    t[:, 0] = rng.integers(0, 60000, n)
+    t[:, 1] = rng.integers(100, 5000, n); t[:, 2] = t[:, 1] - 7; t[:, 3] = 7
+    t[:, 4] = rng.integers(0, 2, n); t[:, 5] = rng.integers(0, 1 << 33, n)
+    t[:, 6:14] = rng.integers(-1, 3000, (n, 8))
+    t[:, 14:30] = 2 ** rng.integers(1, 12, (n, 16))
+    r = results_from_table(t, 1.0, 20, 30, 7, 5000)
+    assert r["scores"] == [int(x) for x in t[:, 0]] and r["total_moves"] == int(t[:, 1].sum())
+    assert r["unfinished"] == int(t[:, 4].sum()) and r["total_expansions"] == int(t[:, 5].sum())
+    assert r["highest_tiles"] == [int(x) for x in t[:, 14:30].max(axis=1)]
+    assert r["best_games"] == sorted(range(n), key=lambda i: t[i, 0], reverse=True)[:5]
+    for k, m in enumerate(MILESTONES):
+        assert r["milestones"][m] == [int(v) for v in t[:, 6 + k] if v >= 0]
+    assert r["final_boards"].shape == (n, 4, 4) and r["summary"]["games"] == n

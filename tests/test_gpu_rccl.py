@@ -76,3 +76,48 @@ def test_rccl_process_group_collectives_and_graph_capture(tmp_path):
     script.write_text(CHILD)
     res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+SHARDED_CHILD = textwrap.dedent("""
+    import os, sys, json
+    sys.path[:0] = [%r, %r]
+    import torch
+    import __graft_entry__ as ge
+    ge.import_package()
+    import g2048
+    from g2048 import dist as gdist
+    dev = torch.device("cuda", 0)                      # both ranks share the one card of the test box
+    torch.cuda.set_device(dev)
+    w, r, lr = gdist.init("gloo", dev)
+    res = g2048.evaluate_beam_search_sharded(45, 8, 6, seed=321, max_moves=400, device=dev, game_id_base=70)
+    gdist.barrier()
+    if r == 0:
+        one = g2048.evaluate_beam_search(45, 8, 6, seed=321, max_moves=400, device=dev, game_id_base=70)
+        keys = ("scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games",
+                "total_expansions", "unfinished", "total_moves", "best_score", "best_game_idx")
+        bad = [k for k in keys if res[k] != one[k]]
+        assert not bad, bad
+        assert (res["final_boards"] == one["final_boards"]).all() and res["parameters"]["world_size"] == 2
+        print("sharded ok")
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+""") % (REPO, PKG)
+
+
+def test_two_rank_sharded_evaluation_equals_one_process(tmp_path):
+    """evaluate_beam_search_sharded with two ranks (gloo, sharing the box's one GPU): 23 + 22 games, the gathered result
+    equals the one-process evaluation of the 45 games -- games are keyed by global id, ranks never talk until the end."""
+    script = tmp_path / "sharded_child.py"
+    script.write_text(SHARDED_CHILD)
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=280) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    assert "sharded ok" in outs[0][0]
