@@ -445,6 +445,21 @@ def main():
                                 "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
                                                                                                 "average_score": 18945.6}}
 
+    # ---- sharded evaluation (N > 1): every rank plays 512 games of one evaluation, one all-gather of the per-game table.
+    # A failure here must not cost the headline line: it is reported, not raised.
+    if not args.no_evaluation and not args.no_beam and world > 1:
+        try:
+            from g2048 import evaluate_beam_search_sharded
+            evs = evaluate_beam_search_sharded(512 * world, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
+            result["evaluation_sharded"] = {"metric": "one beam-search evaluation (width 20, depth 30, 5000-move cap) of 512 games "
+                                                      "per rank, games sharded by contiguous id range, one all-gather at the end",
+                                            "games": len(evs["scores"]), "n_ranks": evs["parameters"]["world_size"],
+                                            "seconds_slowest_rank": evs["elapsed_s"], "moves": evs["total_moves"],
+                                            "rate_2048_or_more": evs["summary"]["rate_2048_or_more"],
+                                            "average_score": evs["summary"]["average_score"]}
+        except Exception as exc:                # noqa: BLE001
+            result["evaluation_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions
     # drawn inside the step kernel (G2048_STEP_RANDOM_ACTIONS; realistic tile distribution instead of the synthetic
     # one), auto-reset on; one hipGraph of 128 step launches
