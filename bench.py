@@ -152,6 +152,18 @@ def timed_replay(graph, ev0, ev1, eager, reps=1):
     return best
 
 
+def beam_roots(ops, n, id_base, dev):
+    """half the roots reached by 200 moves of seeded self-play under a greedy fast-evaluation policy (a
+    width-1, depth-1 beam decision is exactly that: every valid move, its spawn, _fast_evaluate, best one), auto-reset on;
+    half independent cells as in C2 (empty with p = 0.30, else codes uniform 1..11)."""
+    half = n // 2
+    boards, scores = ops.reset(half, SEED + 1, 0, id_base, device=dev)
+    for t in range(200):
+        a, _ = ops.beam_get_action(boards, 1, 1, seed=SEED + 1, step_index=t, game_id_base=id_base)
+        ops.step(boards, a, scores, SEED + 1, t, id_base, out=boards, auto_reset=True)
+    return torch.cat([boards, ops.synth_boards(n - half, seed=SEED + 2, id_base=id_base + half, device=dev)])
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -388,9 +400,7 @@ def main():
 
     # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
     if not args.no_beam:
-        roots = torch.cat([ops.synth_boards(BEAM_GAMES // 2, seed=SEED + 1, id_base=rank * BEAM_GAMES, device=dev),
-                           ops.synth_boards(BEAM_GAMES // 2, seed=SEED + 2, id_base=rank * BEAM_GAMES, p_empty=0.45,
-                                            max_code=9, device=dev)])
+        roots = beam_roots(ops, BEAM_GAMES, rank * BEAM_GAMES, dev)
         for w in range(2):
             a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=w,
                                           game_id_base=rank * BEAM_GAMES, want_expanded=True)

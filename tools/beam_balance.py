@@ -12,8 +12,9 @@ from g2048 import ops
 
 SEED, N, W, D = 0x2048, 4096, 20, 30
 dev = torch.device("cuda")
-roots = torch.cat([ops.synth_boards(N // 2, seed=SEED + 1, id_base=0, device=dev),
-                   ops.synth_boards(N // 2, seed=SEED + 2, id_base=0, p_empty=0.45, max_code=9, device=dev)])
+import bench
+bench.torch = torch
+roots = bench.beam_roots(ops, N, 0, dev)
 
 
 def run(order, reps=20):

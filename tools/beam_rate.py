@@ -9,8 +9,9 @@ from g2048 import ops
 SEED = 0x2048
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda")
-roots = torch.cat([ops.synth_boards(n // 2, seed=SEED + 1, id_base=0, device=dev),
-                   ops.synth_boards(n - n // 2, seed=SEED + 2, id_base=0, p_empty=0.45, max_code=9, device=dev)])
+import bench
+bench.torch = torch
+roots = bench.beam_roots(ops, n, 0, dev)
 for w in range(3):
     ops.beam_get_action(roots, 20, 30, seed=SEED, step_index=w, want_expanded=True)
 torch.cuda.synchronize()
