@@ -5,7 +5,8 @@
 // and the ranking, 64 children per pass; the first `width` write themselves to the beam. Details at beam_decide.
 // Scores are computed in the reference's operation order (bit-exact with the oracle); no MFMA, no global memory
 // traffic inside the search (root in, action out). beam_decide() is the search as a device function; beam_kernel
-// runs it once per game (g2048_beam_get_action), play_kernel loops it with the env step (g2048_play_games).
+// runs it once per game (g2048_beam_get_action); play_kernel / play_spec_kernel loop it with the env step
+// (g2048_play_games), the latter with helper wavefronts that search the next moves' possible roots ahead of time.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
