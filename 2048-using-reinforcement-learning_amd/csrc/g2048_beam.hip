@@ -183,8 +183,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         for (int p = 0; p < PASSES; ++p) rank[p] = 0u;
         if (fast) {
             const uint4 *keys = reinterpret_cast<const uint4 *>(s_score);
+            // the next trip's sixteen keys are requested before this trip's are compared (the last request reads slots
+            // nobody uses; they are inside s_score)
+            uint4 n0 = keys[0], n1 = keys[1], n2 = keys[2], n3 = keys[3];
             for (uint32_t j = 0; j < total_valid; j += 16) {
-                const uint4 q0 = keys[(j >> 2)], q1 = keys[(j >> 2) + 1], q2 = keys[(j >> 2) + 2], q3 = keys[(j >> 2) + 3];
+                const uint4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+                n0 = keys[(j >> 2) + 4]; n1 = keys[(j >> 2) + 5]; n2 = keys[(j >> 2) + 6]; n3 = keys[(j >> 2) + 7];
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
                     const uint32_t me = ikey[p];
