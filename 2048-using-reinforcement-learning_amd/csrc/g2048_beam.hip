@@ -524,10 +524,17 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     return G2048_OK;
 }
 
-int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
+static size_t play_workspace_bytes(size_t n_games)
+{
+    const size_t list_bytes = (n_games * sizeof(uint32_t) + 63u) & ~(size_t)63u;
+    return 64u + list_bytes + n_games * kSpec * sizeof(SpecSlot);
+}
+
+// caller_ws: nullptr = allocate the helper workspace from the stream-ordered allocator (g2048_play_games)
+static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
                      int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
                      int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
-                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, void *caller_ws)
 {
     if (n_games == 0) return G2048_OK;
     if (!boards_inout || !score_inout || !moves_out || !valid_out || !invalid_out || !milestone_move_out || !alive_out) {
@@ -575,10 +582,12 @@ int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         }
         const uint32_t reg_resolved = games_left >= n ? 0u : n - games_left;
         const size_t list_bytes = (n_games * sizeof(uint32_t) + 63u) & ~(size_t)63u;
-        const size_t bytes = 64u + list_bytes + n_games * kSpec * sizeof(SpecSlot);
-        char *ws = nullptr;
-        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, s);
-        if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+        const size_t bytes = play_workspace_bytes(n_games);
+        char *ws = static_cast<char *>(caller_ws);
+        if (!ws) {
+            hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, s);
+            if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+        }
         SpecCtl *ctl = reinterpret_cast<SpecCtl *>(ws);
         uint32_t *reg_list = reinterpret_cast<uint32_t *>(ws + 64);
         SpecSlot *slots = reinterpret_cast<SpecSlot *>(ws + 64 + list_bytes);
@@ -592,12 +601,44 @@ int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         else if (passes == 4) G2048_LAUNCH_PLAY(4);
         else G2048_LAUNCH_PLAY(8);
 #undef G2048_LAUNCH_PLAY
-        (void)hipFreeAsync(ws, s);
+        if (!caller_ws) (void)hipFreeAsync(ws, s);
     }
 #undef G2048_PLAY_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;
+}
+
+int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
+                     int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                     int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
+{
+    return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
+                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     nullptr);
+}
+
+size_t g2048_play_games_workspace(size_t n_games)
+{
+    return (n_games == 0 || n_games > kSpecMaxGames) ? 0 : play_workspace_bytes(n_games);
+}
+
+int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
+                        int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                        int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
+                        uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    const size_t need = g2048_play_games_workspace(n_games);
+    if (!workspace || need == 0) opts |= G2048_PLAY_ONE_PHASE;                  // no scratch: every game on its one wavefront
+    else if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 63u)) {
+        g2048_set_last_error_("g2048_play_games_ws: workspace smaller than g2048_play_games_workspace(n_games) or not 64-byte aligned");
+        return G2048_ERR_ARG;
+    }
+    return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
+                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace);
 }
 
 int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,

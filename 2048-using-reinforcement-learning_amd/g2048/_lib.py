@@ -42,6 +42,9 @@ SIGNATURES = {
     "g2048_simulate_move": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "g2048_simulate_move_sampled": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_play_games": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp]),
+    "g2048_play_games_workspace": (_sz, [_sz]),
+    "g2048_play_games_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp, _sz,
+                                  _vp]),
     "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_unpack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_synth_boards": (_int, [_vp, _u64, _u64, _sz, _u32, _u32, _vp]),

@@ -478,12 +478,15 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
         "milestone_move": torch.full((n, 8), -1, dtype=torch.int32, device=dev),
         "expanded": torch.zeros(n, dtype=torch.int64, device=dev), "alive": torch.zeros(n, dtype=torch.uint8, device=dev),
     }
-    L.call(dev, L.lib().g2048_play_games, boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
+    # the helpers' request slots: caller-owned scratch, like every other buffer of the interface
+    ws_bytes = 0 if one_phase else int(L.lib().g2048_play_games_workspace(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    L.call(dev, L.lib().g2048_play_games_ws, boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
            out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
            out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
            int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
            (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0),
-           L.stream_ptr(dev))
+           ws.data_ptr() if ws is not None else None, ws_bytes, L.stream_ptr(dev))
     return out
 
 

@@ -173,7 +173,8 @@ int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void
  * g2048_beam_get_action(step_index = t, game id g) and g2048_step(step_index = t, board id g), so the outcome equals
  * the step-by-step loop. Unless opts has G2048_PLAY_ONE_PHASE (or n_games > 65,536) the launch also carries helper
  * wavefronts that search the roots a game's next moves can start from ahead of time (same decisions, less latency for the
- * last games; workspace from hipMallocAsync on `stream`, freed in stream order).
+ * last games). They need g2048_play_games_workspace(n_games) bytes of device scratch: g2048_play_games_ws takes it from
+ * the caller (64-byte aligned; NULL = play without helpers), g2048_play_games from hipMallocAsync on `stream`.
  * Outputs per game: final board / score (in place), moves played, valid / invalid move counts,
  * milestone_move_out[g][0..8) = move at which tiles 64..8192 first appeared (-1 = never), total children expanded
  * (optional), alive_out[g] = 1 if the game hit max_moves without finishing. */
@@ -181,6 +182,12 @@ int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
                      int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
                      uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
                      uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream);
+size_t g2048_play_games_workspace(size_t n_games);
+int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
+                        int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
+                        uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
+                        uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);

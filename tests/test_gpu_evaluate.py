@@ -193,3 +193,49 @@ def test_speculative_helpers_tuning_extremes(g2048, monkeypatch):
         for k in PLAY_KEYS:
             assert r0[k] == r1[k], (tune, k)
         assert np.array_equal(r0["final_boards"], r1["final_boards"])
+
+
+def test_play_games_workspace_entry_points(g2048):
+    """g2048_play_games_ws with caller scratch (what ops.play_games uses), with no scratch (= no helpers), with too
+    little (refused), and g2048_play_games allocating its own: all the same games."""
+    from g2048 import ops, _lib as L
+    dev = torch.device("cuda")
+    n, w, d, cap, seed = 40, 12, 6, 500, 606
+
+    def fresh():
+        b, s = ops.reset(n, seed, 0, 0, device=dev)
+        out = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        ms = torch.full((n, 8), -1, dtype=torch.int32, device=dev)
+        ex = torch.zeros(n, dtype=torch.int64, device=dev)
+        al = torch.zeros(n, dtype=torch.uint8, device=dev)
+        return b, s, out, ms, ex, al
+
+    def args(t):
+        b, s, out, ms, ex, al = t
+        return (b.data_ptr(), s.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ms.data_ptr(), ex.data_ptr(),
+                al.data_ptr(), w, d, 512, 1024, cap, L.u64(seed), L.u64(0), n, 0)
+
+    need = int(L.lib().g2048_play_games_workspace(n))
+    assert need >= n * 8 * 64 and int(L.lib().g2048_play_games_workspace(0)) == 0
+    assert int(L.lib().g2048_play_games_workspace((1 << 16) + 1)) == 0          # beyond 65,536 games: no helpers
+    results = []
+    for mode in ("ws", "null", "own"):
+        t = fresh()
+        if mode == "ws":
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            L.call(dev, L.lib().g2048_play_games_ws, *args(t), ws.data_ptr(), need, L.stream_ptr(dev))
+        elif mode == "null":
+            L.call(dev, L.lib().g2048_play_games_ws, *args(t), None, 0, L.stream_ptr(dev))
+        else:
+            L.call(dev, L.lib().g2048_play_games, *args(t), L.stream_ptr(dev))
+        torch.cuda.synchronize()
+        b, s, out, ms, ex, al = t
+        results.append([x.cpu() for x in (b, s, *out, ms, ex, al)])
+    for r in results[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(results[0], r))
+    t = fresh()
+    small = torch.empty(need - 64, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="workspace"):
+        L.call(dev, L.lib().g2048_play_games_ws, *args(t), small.data_ptr(), need - 64, L.stream_ptr(dev))
+    with pytest.raises(RuntimeError, match="workspace"):
+        L.call(dev, L.lib().g2048_play_games_ws, *args(t), small.data_ptr() + 16, need, L.stream_ptr(dev))      # misaligned
