@@ -28,6 +28,101 @@ __device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
+// ---------------------------------------------------------------- ranking by sorting network
+// The fast levels rank unique 32-bit keys (score * 512 + 511 - generation index). All-pairs counting costs ~1.5 VALU
+// instructions per (key, lane) pair -- 190 to 240 per level at width 20 and two fifths of a decision's time. A bitonic
+// network sorts the 64 keys a wavefront holds, one per lane, in 21 compare-exchange steps of 3 to 5 instructions: the
+// partner of lane e at distance j is e ^ j, reached through DPP for j = 1, 2 (quad_perm), 4 (quad reverse, then half-row
+// mirror), 8 (row rotate by 8) -- folded into the v_max / v_min that consume it -- and through gfx950's
+// v_permlane16_swap / v_permlane32_swap for j = 16, 32; which of the pair keeps the larger key is a compile-time lane mask
+// (an SGPR pair feeding v_cndmask).
+constexpr uint64_t cx_mask(int k, int j)         // lanes that keep the LARGER key in step (k, j) of a descending sort
+{
+    uint64_t m = 0;
+    for (int e = 0; e < 64; ++e) {
+        const bool desc = k >= 64 || (e & k) == 0, lower = (e & j) == 0;
+        if (desc == lower) m |= 1ull << e;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t pick_by_mask(uint32_t if0, uint32_t if1, uint64_t mask)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_of(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+
+template <int K, int J>
+__device__ __forceinline__ uint32_t cx_step(uint32_t key)
+{
+    constexpr uint64_t keep_max = cx_mask(K, J);
+    uint32_t hi, lo;
+    if (J == 1) { hi = max(dpp_of<0xB1>(key), key); lo = min(dpp_of<0xB1>(key), key); }              // quad_perm [1,0,3,2]
+    else if (J == 2) { hi = max(dpp_of<0x4E>(key), key); lo = min(dpp_of<0x4E>(key), key); }         // quad_perm [2,3,0,1]
+    else if (J == 4) {                                                                               // e ^ 3, then e ^ 7
+        const uint32_t r = dpp_of<0x1B>(key);                                                        // quad_perm [3,2,1,0]
+        hi = max(dpp_of<0x141>(r), key); lo = min(dpp_of<0x141>(r), key);                            // row_half_mirror
+    } else if (J == 8) { hi = max(dpp_of<0x128>(key), key); lo = min(dpp_of<0x128>(key), key); }     // row_ror:8
+    else if (J == 16) {                          // odd rows of one copy <-> even rows of the other: both lanes of a pair see both keys
+        const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+        hi = max(r[0], r[1]); lo = min(r[0], r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+        hi = max(r[0], r[1]); lo = min(r[0], r[1]);
+    }
+    return pick_by_mask(lo, hi, keep_max);
+}
+
+// stages k = 2 .. KMAX of the 64-lane descending network: KMAX = 64 sorts the wavefront's keys, descending by lane; KMAX = 16
+// leaves every 16-lane row sorted, rows 0 and 2 descending, rows 1 and 3 ASCENDING
+template <int KMAX>
+__device__ __forceinline__ uint32_t sort_stages(uint32_t key)
+{
+    key = cx_step<2, 1>(key);
+    key = cx_step<4, 2>(key); key = cx_step<4, 1>(key);
+    key = cx_step<8, 4>(key); key = cx_step<8, 2>(key); key = cx_step<8, 1>(key);
+    key = cx_step<16, 8>(key); key = cx_step<16, 4>(key); key = cx_step<16, 2>(key); key = cx_step<16, 1>(key);
+    if (KMAX >= 32) {
+        key = cx_step<32, 16>(key); key = cx_step<32, 8>(key); key = cx_step<32, 4>(key); key = cx_step<32, 2>(key);
+        key = cx_step<32, 1>(key);
+    }
+    if (KMAX >= 64) {
+        key = cx_step<64, 32>(key); key = cx_step<64, 16>(key); key = cx_step<64, 8>(key); key = cx_step<64, 4>(key);
+        key = cx_step<64, 2>(key); key = cx_step<64, 1>(key);
+    }
+    return key;
+}
+
+// the last stage alone: sorts a sequence that descends and then ascends (bitonic) into descending order
+__device__ __forceinline__ uint32_t merge64_desc(uint32_t key)
+{
+    key = cx_step<64, 32>(key); key = cx_step<64, 16>(key); key = cx_step<64, 8>(key); key = cx_step<64, 4>(key);
+    key = cx_step<64, 2>(key); key = cx_step<64, 1>(key);
+    return key;
+}
+
+// The 64 largest of up to 80 keys, descending by lane: a = one key per lane, b = up to 16 more in lanes 48..63 (0 elsewhere
+// and for "no key"; real keys are > 0). with_b is wave-uniform. The 16 smallest of a cannot be among the first 48 of the
+// union, which is all a beam of width <= 32 takes.
+__device__ __forceinline__ uint32_t top64_desc(uint32_t a, uint32_t b, bool with_b)
+{
+    a = sort_stages<64>(a);
+    if (!with_b) return a;
+    b = sort_stages<16>(b);                                       // row 3 ascending
+    return merge64_desc(pick_by_mask(a, b, 0xffff000000000000ull));
+}
+
+__global__ __launch_bounds__(64) void sort_selftest_kernel(uint32_t *keys, const uint32_t *extra, int with_extra)
+{
+    const uint32_t a = keys[blockIdx.x * 64 + threadIdx.x];
+    const uint32_t b = (with_extra && threadIdx.x >= 48) ? extra[blockIdx.x * 16 + threadIdx.x - 48] : 0u;
+    keys[blockIdx.x * 64 + threadIdx.x] = top64_desc(a, b, with_extra != 0);
+}
+
 // LDS of one search (one wavefront = one game). A level can have 4 * width valid children; they are scored and ranked 64 at a
 // time, so PASSES = ceil(4 * width / 64): 1 for width <= 16, 2 up to 32 (the reference's evaluation width is 20), 4 up to 64,
 // 8 up to 128.
@@ -139,6 +234,10 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         }
         __syncthreads();
         // ---- stage B: spawn + score of the compacted children, one per lane and pass (a pass only runs if it has children)
+        // Ranking by sorting network (above) on the fast levels of beams up to 32 wide, when the level has 17 .. 80 children
+        // (wave-uniform): then the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the
+        // network wants their keys.
+        const bool net = PASSES <= 2 && fast && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u);
         Board child[PASSES];
         double score[PASSES];
         uint32_t ikey[PASSES], cinfo[PASSES];          // cinfo: root action | max code << 8 of the spawned child
@@ -146,8 +245,9 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         for (int p = 0; p < PASSES; ++p) {
             score[p] = -INFINITY; ikey[p] = 0u; cinfo[p] = 0u; child[p] = root;
             if ((uint32_t)(p * 64) < total_valid) {                              // wave-uniform
-                const uint32_t ci = (uint32_t)(p * 64) + lane;
-                const bool live = ci < total_valid;
+                const bool tail_row = net && p == 1;
+                const uint32_t ci = tail_row ? lane + 16u : (uint32_t)(p * 64) + lane;
+                const bool live = ci < total_valid && (!tail_row || lane >= 48u);
                 const uint4 cv = s_cboard[live ? ci : 0u];
                 Board c = {{cv.x, cv.y, cv.z, cv.w}};
                 const uint32_t cr = s_croot[live ? ci : 0u];
@@ -167,13 +267,36 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 cinfo[p] = (cr & 0xffu) | (cmax << 8);
                 if (fast) {
                     ikey[p] = live ? (eval_fast_u32_known(c, n_child, cmax) << 9) + (511u - ci) : 0u;
-                    reinterpret_cast<uint32_t *>(s_score)[ci] = ikey[p];         // ci < 64 * PASSES always
+                    if (!net) reinterpret_cast<uint32_t *>(s_score)[ci] = ikey[p];       // ci < 64 * PASSES always
                 } else {
                     score[p] = live ? eval_full_known(c, phase, n_child, cmax) : -INFINITY;
                     s_score[ci] = score[p];
                 }
                 child[p] = c;
             }
+        }
+        if (net) {
+            // the spawned children go back to their LDS slots, the keys are sorted in registers, and lane r takes the child
+            // whose key came r-th (the keys are unique, so this is the stable descending order of :131 / :174)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const bool tail_row = p == 1;
+                const uint32_t ci = tail_row ? lane + 16u : lane;
+                if (ci < total_valid && (!tail_row || lane >= 48u)) {
+                    s_cboard[ci] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
+                    s_croot[ci] = cinfo[p];
+                }
+            }
+            const uint32_t sorted = top64_desc(ikey[0], PASSES == 2 ? ikey[PASSES - 1] : 0u, PASSES == 2 && total_valid > 64u);
+            __syncthreads();
+            nb = (int)min(total_valid, (uint32_t)width);
+            if ((int)lane < nb) {
+                const uint32_t ci = 511u - (sorted & 511u);
+                s_board[lane] = s_cboard[ci];
+                s_root[lane] = s_croot[ci];
+            }
+            __syncthreads();
+            continue;
         }
         __syncthreads();
         // ---- stable descending rank (:131, :174) among the valid children. Every pass that ran wrote all its 64 slots (zeros
@@ -639,6 +762,17 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
     return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
                      alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
                      (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace);
+}
+
+int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, void *stream)
+{
+    if (n_waves == 0) return G2048_OK;
+    if (!keys_inout || n_waves > 0x7fffffffu) { g2048_set_last_error_("g2048_sort_selftest: bad arguments"); return G2048_ERR_ARG; }
+    hipLaunchKernelGGL(sort_selftest_kernel, dim3((unsigned)n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), keys_inout,
+                       extra_or_null, extra_or_null ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
+    return G2048_OK;
 }
 
 int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,

@@ -168,3 +168,30 @@ def test_beam_widths_dead_roots_huge_tiles_masks(ops, oracle, width, depth, n):
                                        game_id_base=(1 << 33) + 9)
         assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(p.cpu().numpy(), op)
         assert np.array_equal(e.cpu().numpy().astype(np.uint32), oe)
+
+
+def test_ranking_network_sorts(ops):
+    """The beam kernel's bitonic network (DPP / v_permlane swaps) alone: 64 keys per wavefront sorted descending; with 16
+    extra keys in the last row, the first 48 positions are the 48 largest of all 80, descending."""
+    from g2048 import _lib as L
+    g = torch.Generator().manual_seed(5)
+    n_waves = 512
+    vals = (torch.randperm(1 << 24, generator=g)[: n_waves * 80] + 1).to(torch.int64)
+    keys = vals[: n_waves * 64].reshape(n_waves, 64).clone()
+    extra = vals[n_waves * 64:].reshape(n_waves, 16).clone()
+    keys[3, 40:] = 0                                    # "no key" lanes
+    keys[4, :] = 0
+    keys[5] = torch.arange(64, 0, -1)                   # already sorted / reversed inputs
+    keys[6] = torch.arange(1, 65)
+    extra[7, 5:] = 0                                    # fewer than 16 extra keys
+    extra[8, :] = 0
+    extra[9] = torch.arange(1 << 25, (1 << 25) + 16)    # every extra key beats every base key
+    dk = keys.to(torch.int32).to(DEV).contiguous()
+    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), None, n_waves, L.stream_ptr(dk.device))
+    want = torch.sort(keys, dim=1, descending=True).values
+    assert torch.equal(dk.cpu().to(torch.int64), want)
+    dk = keys.to(torch.int32).to(DEV).contiguous()
+    de = extra.to(torch.int32).to(DEV).contiguous()
+    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), de.data_ptr(), n_waves, L.stream_ptr(dk.device))
+    want = torch.sort(torch.cat([keys, extra], dim=1), dim=1, descending=True).values[:, :48]
+    assert torch.equal(dk.cpu().to(torch.int64)[:, :48], want)
