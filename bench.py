@@ -442,12 +442,10 @@ def main():
     if not args.no_evaluation and not args.no_beam and world == 1:
         from g2048 import evaluate_beam_search
         evaluate_beam_search(256, BEAM_WIDTH, BEAM_DEPTH, seed=1, max_moves=50, device=dev)      # warm
-        def best_of_two(games, **kw):
-            runs = [evaluate_beam_search(games, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev, **kw) for _ in range(2)]
-            return min(runs, key=lambda r: r["elapsed_s"])
-        ev = best_of_two(BEAM_GAMES)
-        ev1 = best_of_two(BEAM_GAMES, one_phase=True)
-        ev100 = best_of_two(100)
+        def play(games, **kw):
+            return evaluate_beam_search(games, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev, **kw)
+        runs = [(play(BEAM_GAMES, one_phase=True), play(BEAM_GAMES), play(100)) for _ in range(2)]     # interleaved, best of two
+        ev1, ev, ev100 = (min((r[k] for r in runs), key=lambda x: x["elapsed_s"]) for k in range(3))
         sm = ev["summary"]
         result["evaluation"] = {"metric": "4096 complete beam-search games (width 20, depth 30, 5000-move cap), one launch",
                                 "seconds": ev["elapsed_s"], "seconds_without_helper_wavefronts": ev1["elapsed_s"],
