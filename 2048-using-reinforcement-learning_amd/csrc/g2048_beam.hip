@@ -145,11 +145,12 @@ struct Decision { uint32_t action; float prob; uint32_t expanded; };
 //     rank, action);
 //   stage B, 64 children per pass: the spawn -- child j of the decision takes draw j, exactly as the Python loop consumes
 //     its RNG -- and the heuristic score, fed the empty count and max code the kernel already knows; key / score to LDS;
-//   ranking: every child counts the children that sort before it (score descending, generation order ascending = Python's
-//     stable sorted(reverse=True)) with broadcast LDS reads, sixteen keys per trip so that the reads of a trip are in flight
-//     together; the first `width` write themselves to the beam at their rank. _fast_evaluate is integer-valued, so on its
-//     levels (0 and >= 4) the pair (score, order) is the single unique integer score * 512 + (511 - index) and a
-//     comparison is one v_cmp_gt_u32; levels 1..3 (_evaluate_state) compare f64 scores.
+//   ranking: the order of Python's stable sorted(reverse=True) (score descending, generation order ascending).
+//     _fast_evaluate is integer-valued, so on its levels (0 and >= 4) the pair (score, order) is the single unique integer
+//     score * 512 + (511 - index); beams up to 32 wide sort those keys with the network above (top64_desc) and lane r copies
+//     the r-th child into the beam. Everywhere else (levels 1..3 with their f64 scores, very small or very large levels, wider
+//     beams) every child counts the children that sort before it, with broadcast LDS reads, sixteen keys per trip so that the
+//     reads of a trip are in flight together, and the first `width` write themselves to the beam at their rank.
 // Tried and measured slower on MI355X (profiles/r02_beam_*.txt): four games per 256-thread block sharing one pass for
 // everybody's leftover children (17 % fewer VALU instructions, but twice the barrier wait); a radix select of the top-k keys
 // with wave ballots instead of the all-pairs count (8 % fewer VALU, 2x the SALU, slower); one wavefront per 64-child group
