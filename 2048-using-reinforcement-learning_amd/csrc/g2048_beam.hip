@@ -116,8 +116,86 @@ __device__ __forceinline__ uint32_t top64_desc(uint32_t a, uint32_t b, bool with
     return merge64_desc(pick_by_mask(a, b, 0xffff000000000000ull));
 }
 
-__global__ __launch_bounds__(64) void sort_selftest_kernel(uint32_t *keys, const uint32_t *extra, int with_extra)
+// The same network on 64-bit keys (hi, lo) for the levels whose scores are f64 (1..3): the partner's two words come through
+// DPP moves or the permlane swaps, one v_cmp_gt_u64 decides, and which side a lane takes is the compare mask XNOR the step's
+// keep-the-larger mask (scalar unit).
+struct Key64 { uint32_t hi, lo; };
+
+__device__ __forceinline__ Key64 take_by_compare(const Key64 &x, const Key64 &y, uint64_t keep_max)
 {
+    // both lanes of a pair hold the same (x, y) up to order; the lane that keeps the larger takes x iff x > y
+    const uint64_t kx = ((uint64_t)x.hi << 32) | x.lo, ky = ((uint64_t)y.hi << 32) | y.lo;
+    const uint64_t x_gt = __ballot(kx > ky);
+    const uint64_t take_x = ~(x_gt ^ keep_max);
+    return Key64{pick_by_mask(y.hi, x.hi, take_x), pick_by_mask(y.lo, x.lo, take_x)};
+}
+
+template <int K, int J>
+__device__ __forceinline__ Key64 cx_step64(const Key64 &key)
+{
+    constexpr uint64_t keep_max = cx_mask(K, J);
+    if (J == 16) {
+        const auto h = __builtin_amdgcn_permlane16_swap(key.hi, key.hi, false, false);
+        const auto l = __builtin_amdgcn_permlane16_swap(key.lo, key.lo, false, false);
+        return take_by_compare(Key64{h[0], l[0]}, Key64{h[1], l[1]}, keep_max);
+    }
+    if (J == 32) {
+        const auto h = __builtin_amdgcn_permlane32_swap(key.hi, key.hi, false, false);
+        const auto l = __builtin_amdgcn_permlane32_swap(key.lo, key.lo, false, false);
+        return take_by_compare(Key64{h[0], l[0]}, Key64{h[1], l[1]}, keep_max);
+    }
+    Key64 o;
+    if (J == 1) o = Key64{dpp_of<0xB1>(key.hi), dpp_of<0xB1>(key.lo)};
+    else if (J == 2) o = Key64{dpp_of<0x4E>(key.hi), dpp_of<0x4E>(key.lo)};
+    else if (J == 4) o = Key64{dpp_of<0x141>(dpp_of<0x1B>(key.hi)), dpp_of<0x141>(dpp_of<0x1B>(key.lo))};
+    else o = Key64{dpp_of<0x128>(key.hi), dpp_of<0x128>(key.lo)};
+    // here x = the partner's key, y = this lane's: take the partner's iff (partner > mine) == (this lane keeps the larger)
+    return take_by_compare(o, key, keep_max);
+}
+
+template <int KMAX>
+__device__ __forceinline__ Key64 sort_stages64(Key64 key)
+{
+    key = cx_step64<2, 1>(key);
+    key = cx_step64<4, 2>(key); key = cx_step64<4, 1>(key);
+    key = cx_step64<8, 4>(key); key = cx_step64<8, 2>(key); key = cx_step64<8, 1>(key);
+    key = cx_step64<16, 8>(key); key = cx_step64<16, 4>(key); key = cx_step64<16, 2>(key); key = cx_step64<16, 1>(key);
+    if (KMAX >= 32) {
+        key = cx_step64<32, 16>(key); key = cx_step64<32, 8>(key); key = cx_step64<32, 4>(key); key = cx_step64<32, 2>(key);
+        key = cx_step64<32, 1>(key);
+    }
+    if (KMAX >= 64) {
+        key = cx_step64<64, 32>(key); key = cx_step64<64, 16>(key); key = cx_step64<64, 8>(key); key = cx_step64<64, 4>(key);
+        key = cx_step64<64, 2>(key); key = cx_step64<64, 1>(key);
+    }
+    return key;
+}
+
+__device__ __forceinline__ Key64 top64_desc64(Key64 a, Key64 b, bool with_b)
+{
+    a = sort_stages64<64>(a);
+    if (!with_b) return a;
+    b = sort_stages64<16>(b);
+    Key64 c = {pick_by_mask(a.hi, b.hi, 0xffff000000000000ull), pick_by_mask(a.lo, b.lo, 0xffff000000000000ull)};
+    c = cx_step64<64, 32>(c); c = cx_step64<64, 16>(c); c = cx_step64<64, 8>(c); c = cx_step64<64, 4>(c);
+    c = cx_step64<64, 2>(c); c = cx_step64<64, 1>(c);
+    return c;
+}
+
+__global__ __launch_bounds__(64) void sort_selftest_kernel(uint32_t *keys, const uint32_t *extra, int with_extra, int wide)
+{
+    if (wide) {                                  // 64-bit keys: (lo, hi) word pairs
+        const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+        const Key64 a = {keys[2 * i + 1], keys[2 * i]};
+        Key64 b = {0u, 0u};
+        if (with_extra && threadIdx.x >= 48) {
+            const size_t e = (size_t)blockIdx.x * 16 + threadIdx.x - 48;
+            b = Key64{extra[2 * e + 1], extra[2 * e]};
+        }
+        const Key64 r = top64_desc64(a, b, with_extra != 0);
+        keys[2 * i] = r.lo; keys[2 * i + 1] = r.hi;
+        return;
+    }
     const uint32_t a = keys[blockIdx.x * 64 + threadIdx.x];
     const uint32_t b = (with_extra && threadIdx.x >= 48) ? extra[blockIdx.x * 16 + threadIdx.x - 48] : 0u;
     keys[blockIdx.x * 64 + threadIdx.x] = top64_desc(a, b, with_extra != 0);
@@ -235,20 +313,23 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         }
         __syncthreads();
         // ---- stage B: spawn + score of the compacted children, one per lane and pass (a pass only runs if it has children)
-        // Ranking by sorting network (above) on the fast levels of beams up to 32 wide, when the level has 17 .. 80 children
-        // (wave-uniform): then the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the
-        // network wants their keys.
-        const bool net = PASSES <= 2 && fast && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u);
+        // Ranking by sorting network (above) for beams up to 32 wide, when the level has 17 .. 80 children (wave-uniform): then
+        // the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the network wants their keys.
+        const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u);
         Board child[PASSES];
         double score[PASSES];
         uint32_t ikey[PASSES], cinfo[PASSES];          // cinfo: root action | max code << 8 of the spawned child
+        uint32_t cidx[PASSES];                         // the child this lane holds in pass p ...
+        bool livep[PASSES];                            // ... if any
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             score[p] = -INFINITY; ikey[p] = 0u; cinfo[p] = 0u; child[p] = root;
+            const bool tail_row = net && p == 1;
+            cidx[p] = tail_row ? lane + 16u : (uint32_t)(p * 64) + lane;
+            livep[p] = cidx[p] < total_valid && (!tail_row || lane >= 48u);
             if ((uint32_t)(p * 64) < total_valid) {                              // wave-uniform
-                const bool tail_row = net && p == 1;
-                const uint32_t ci = tail_row ? lane + 16u : (uint32_t)(p * 64) + lane;
-                const bool live = ci < total_valid && (!tail_row || lane >= 48u);
+                const uint32_t ci = cidx[p];
+                const bool live = livep[p];
                 const uint4 cv = s_cboard[live ? ci : 0u];
                 Board c = {{cv.x, cv.y, cv.z, cv.w}};
                 const uint32_t cr = s_croot[live ? ci : 0u];
@@ -271,33 +352,60 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                     if (!net) reinterpret_cast<uint32_t *>(s_score)[ci] = ikey[p];       // ci < 64 * PASSES always
                 } else {
                     score[p] = live ? eval_full_known(c, phase, n_child, cmax) : -INFINITY;
-                    s_score[ci] = score[p];
+                    if (!tail_row || lane >= 48u) s_score[ci] = score[p];        // (the tail row's idle lanes own no slot)
                 }
                 child[p] = c;
             }
         }
         if (net) {
             // the spawned children go back to their LDS slots, the keys are sorted in registers, and lane r takes the child
-            // whose key came r-th (the keys are unique, so this is the stable descending order of :131 / :174)
+            // whose key came r-th
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const bool tail_row = p == 1;
-                const uint32_t ci = tail_row ? lane + 16u : lane;
-                if (ci < total_valid && (!tail_row || lane >= 48u)) {
-                    s_cboard[ci] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
-                    s_croot[ci] = cinfo[p];
+            for (int p = 0; p < PASSES; ++p)
+                if (livep[p]) {
+                    s_cboard[cidx[p]] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
+                    s_croot[cidx[p]] = cinfo[p];
+                }
+            const bool with_tail = PASSES == 2 && total_valid > 64u;
+            nb = (int)min(total_valid, (uint32_t)width);
+            uint32_t pick;
+            bool exact = true;
+            if (fast) {
+                // the keys are unique, so their descending order is the stable order of :131 / :174
+                pick = 511u - (top64_desc(ikey[0], PASSES == 2 ? ikey[PASSES - 1] : 0u, with_tail) & 511u);
+            } else {
+                // f64 scores as order-preserving unsigned keys (sign bit flipped, negative values complemented; the score
+                // is never -0.0 or NaN), the low seven bits replaced by 127 - generation index: equal scores then sort in
+                // generation order, as Python's stable sort leaves them. Two scores that differ ONLY in those seven bits
+                // would be misordered: if neighbours among the first `width` + 1 agree in everything else, their scores
+                // are read back, and unless they are equal the level goes to the counting loop below instead.
+                Key64 k[PASSES];
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(score[p]);
+                    uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+                    const uint32_t neg = (uint32_t)((int32_t)hi >> 31);
+                    hi ^= neg | 0x80000000u; lo ^= neg;
+                    k[p] = livep[p] ? Key64{hi, (lo & ~127u) | (127u - cidx[p])} : Key64{0u, 0u};
+                }
+                const Key64 sorted = top64_desc64(k[0], k[PASSES - 1], with_tail);
+                const uint32_t nhi = (uint32_t)__shfl_down((int)sorted.hi, 1, 64), nlo = (uint32_t)__shfl_down((int)sorted.lo, 1, 64);
+                const bool close = (int)lane < nb && lane < 63u && sorted.hi == nhi && ((sorted.lo ^ nlo) < 128u) && (nhi | nlo) != 0u;
+                pick = 127u - (sorted.lo & 127u);
+                if (__ballot(close)) {                  // equal scores (common: transpositions) or scores a few ulp apart?
+                    const double mine = s_score[pick], next = __shfl_down(mine, 1, 64);
+                    exact = __ballot(close && mine != next) == 0ull;
                 }
             }
-            const uint32_t sorted = top64_desc(ikey[0], PASSES == 2 ? ikey[PASSES - 1] : 0u, PASSES == 2 && total_valid > 64u);
-            __syncthreads();
-            nb = (int)min(total_valid, (uint32_t)width);
-            if ((int)lane < nb) {
-                const uint32_t ci = 511u - (sorted & 511u);
-                s_board[lane] = s_cboard[ci];
-                s_root[lane] = s_croot[ci];
+            if (exact) {
+                __syncthreads();
+                if ((int)lane < nb) {
+                    s_board[lane] = s_cboard[pick];
+                    s_root[lane] = s_croot[pick];
+                }
+                __syncthreads();
+                continue;
             }
-            __syncthreads();
-            continue;
         }
         __syncthreads();
         // ---- stable descending rank (:131, :174) among the valid children. Every pass that ran wrote all its 64 slots (zeros
@@ -327,7 +435,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
-                    const uint32_t ci = (uint32_t)(p * 64) + lane;
+                    const uint32_t ci = cidx[p];
                     rank[p] += (sj.x > score[p] || (sj.x == score[p] && j < ci)) ? 1u : 0u;
                     rank[p] += (sj.y > score[p] || (sj.y == score[p] && j + 1 < ci)) ? 1u : 0u;
                 }
@@ -335,8 +443,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const uint32_t ci = (uint32_t)(p * 64) + lane;
-            if (ci < total_valid && rank[p] < (uint32_t)width) {                  // :132 / :175
+            if (livep[p] && rank[p] < (uint32_t)width) {                          // :132 / :175
                 s_board[rank[p]] = make_uint4(child[p].w[0], child[p].w[1], child[p].w[2], child[p].w[3]);
                 s_root[rank[p]] = cinfo[p];
             }
@@ -765,12 +872,14 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
                      (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace);
 }
 
-int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, void *stream)
+int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream)
 {
     if (n_waves == 0) return G2048_OK;
-    if (!keys_inout || n_waves > 0x7fffffffu) { g2048_set_last_error_("g2048_sort_selftest: bad arguments"); return G2048_ERR_ARG; }
+    if (!keys_inout || n_waves > 0x7fffffffu || (key_bits != 32 && key_bits != 64)) {
+        g2048_set_last_error_("g2048_sort_selftest: bad arguments"); return G2048_ERR_ARG;
+    }
     hipLaunchKernelGGL(sort_selftest_kernel, dim3((unsigned)n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), keys_inout,
-                       extra_or_null, extra_or_null ? 1 : 0);
+                       extra_or_null, extra_or_null ? 1 : 0, key_bits == 64 ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;

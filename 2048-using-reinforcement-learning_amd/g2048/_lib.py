@@ -56,7 +56,7 @@ SIGNATURES = {
     "g2048_sample_actions_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _sz, _vp]),
     "g2048_track_episodes_dyn": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "g2048_selftest": (_int, [_vp, _vp]),
-    "g2048_sort_selftest": (_int, [_vp, _vp, _sz, _vp]),
+    "g2048_sort_selftest": (_int, [_vp, _vp, _sz, _int, _vp]),
     "g2048_rollout_step": (_int, [_vp] * 13 + [_u64, _u64, _vp, _u64, _sz, _u32, _vp]),
     "g2048_shaping_scan_workspace": (_sz, [_sz]),
     "g2048_shaping_scan": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),

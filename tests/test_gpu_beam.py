@@ -187,11 +187,41 @@ def test_ranking_network_sorts(ops):
     extra[8, :] = 0
     extra[9] = torch.arange(1 << 25, (1 << 25) + 16)    # every extra key beats every base key
     dk = keys.to(torch.int32).to(DEV).contiguous()
-    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), None, n_waves, L.stream_ptr(dk.device))
+    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), None, n_waves, 32, L.stream_ptr(dk.device))
     want = torch.sort(keys, dim=1, descending=True).values
     assert torch.equal(dk.cpu().to(torch.int64), want)
     dk = keys.to(torch.int32).to(DEV).contiguous()
     de = extra.to(torch.int32).to(DEV).contiguous()
-    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), de.data_ptr(), n_waves, L.stream_ptr(dk.device))
+    L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), de.data_ptr(), n_waves, 32, L.stream_ptr(dk.device))
     want = torch.sort(torch.cat([keys, extra], dim=1), dim=1, descending=True).values[:, :48]
     assert torch.equal(dk.cpu().to(torch.int64)[:, :48], want)
+
+
+def test_ranking_network_sorts_64_bit_keys(ops):
+    """The 64-bit variant (levels whose scores are f64): keys differing only in the high word, only in the low word, above
+    2^63 and below 2^31."""
+    from g2048 import _lib as L
+    g = torch.Generator().manual_seed(9)
+    n_waves = 256
+    lo = torch.randint(0, 1 << 32, (n_waves, 80), generator=g, dtype=torch.int64)
+    hi = torch.randint(0, 1 << 32, (n_waves, 80), generator=g, dtype=torch.int64)
+    hi[0] = 7                                           # equal high words: the low word decides
+    hi[1, :40] = 0                                      # keys below 2^32
+    hi[2] = torch.randint(0, 4, (80,), generator=g)     # many equal high words
+    lo[3] = 5                                           # equal low words
+    hi[4] = torch.randint((1 << 32) - 4, 1 << 32, (80,), generator=g)       # top bit set: an unsigned compare is needed
+    def words32(x):                                     # (n, m, 2) words in [0, 2^32) -> int32 bit patterns on the device
+        x = x.reshape(x.shape[0], -1)
+        return torch.where(x >= (1 << 31), x - (1 << 32), x).to(torch.int32).to(DEV).contiguous()
+
+    for with_extra in (False, True):
+        dk = words32(torch.stack([lo[:, :64], hi[:, :64]], dim=2))
+        de = words32(torch.stack([lo[:, 64:], hi[:, 64:]], dim=2)) if with_extra else None
+        L.call(dk.device, L.lib().g2048_sort_selftest, dk.data_ptr(), de.data_ptr() if de is not None else None, n_waves, 64,
+               L.stream_ptr(dk.device))
+        out = dk.cpu().to(torch.int64) & 0xffffffff
+        m, keep = (80, 48) if with_extra else (64, 64)
+        for w in range(n_waves):
+            got = [(int(out[w, 2 * i + 1]) << 32) | int(out[w, 2 * i]) for i in range(keep)]
+            want = sorted(((int(hi[w, i]) << 32) | int(lo[w, i]) for i in range(m)), reverse=True)[:keep]
+            assert got == want, (w, with_extra)
