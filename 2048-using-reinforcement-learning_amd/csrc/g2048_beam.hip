@@ -236,7 +236,7 @@ struct Decision { uint32_t action; float prob; uint32_t expanded; };
 template <int PASSES>
 __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Board &root, int mask_in, int width, int depth,
                                                 uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1, uint64_t gid,
-                                                bool fixed_down)
+                                                uint32_t flags)
 {
     uint4 *const s_board = sh.board;
     uint32_t *const s_root = sh.root;
@@ -244,6 +244,8 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     uint32_t *const s_croot = sh.croot;
     double *const s_score = sh.score;
     const uint32_t lane = threadIdx.x;
+    const bool fixed_down = (flags & 1u) != 0u;          // G2048_BEAM_FIXED_DOWN
+    const bool count_rank = (flags & 2u) != 0u;          // G2048_BEAM_RANK_BY_COUNTING
 
     // :82-93 -- caller mask or the agent's own validity; 0 or 1 valid move short-circuit
     const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);
@@ -315,7 +317,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         // ---- stage B: spawn + score of the compacted children, one per lane and pass (a pass only runs if it has children)
         // Ranking by sorting network (above) for beams up to 32 wide, when the level has 17 .. 80 children (wave-uniform): then
         // the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the network wants their keys.
-        const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u);
+        const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u) && !(count_rank && fast);
         Board child[PASSES];
         double score[PASSES];
         uint32_t ikey[PASSES], cinfo[PASSES];          // cinfo: root action | max code << 8 of the spawned child
@@ -369,7 +371,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             const bool with_tail = PASSES == 2 && total_valid > 64u;
             nb = (int)min(total_valid, (uint32_t)width);
             uint32_t pick;
-            bool exact = true;
+            bool exact = !count_rank;                  // (the test switch: laid out for the network, ranked by counting)
             if (fast) {
                 // the keys are unique, so their descending order is the stable order of :131 / :174
                 pick = 511u - (top64_desc(ikey[0], PASSES == 2 ? ikey[PASSES - 1] : 0u, with_tail) & 511u);
@@ -392,7 +394,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 const uint32_t nhi = (uint32_t)__shfl_down((int)sorted.hi, 1, 64), nlo = (uint32_t)__shfl_down((int)sorted.lo, 1, 64);
                 const bool close = (int)lane < nb && lane < 63u && sorted.hi == nhi && ((sorted.lo ^ nlo) < 128u) && (nhi | nlo) != 0u;
                 pick = 127u - (sorted.lo & 127u);
-                if (__ballot(close)) {                  // equal scores (common: transpositions) or scores a few ulp apart?
+                if (exact && __ballot(close)) {         // equal scores (common: transpositions) or scores a few ulp apart?
                     const double mine = s_score[pick], next = __shfl_down(mine, 1, 64);
                     exact = __ballot(close && mine != next) == 0ull;
                 }
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
                                                  uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
                                                  uint32_t *__restrict__ expanded_out, int width, int depth,
                                                  uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
-                                                 uint64_t id_base, bool fixed_down, const uint32_t *__restrict__ keyblock)
+                                                 uint64_t id_base, uint32_t flags, const uint32_t *__restrict__ keyblock)
 {
     if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
     __shared__ BeamShared<PASSES> sh;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     const uint4 rv = roots[g];
     const Board root = {{rv.x, rv.y, rv.z, rv.w}};
     const Decision d = beam_decide<PASSES>(sh, root, mask_in ? (int)(mask_in[g] & 15u) : -1, width, depth, early_thr, mid_thr,
-                                           k0, k1, id_base + g, fixed_down);
+                                           k0, k1, id_base + g, flags);
     if (threadIdx.x == 0) {
         action_out[g] = (uint8_t)d.action;
         prob_out[g] = d.prob;
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
                                                  int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
                                                  unsigned long long *__restrict__ expanded_out, uint8_t *__restrict__ alive_out,
                                                  int width, int depth, uint32_t early_thr, uint32_t mid_thr, int max_moves,
-                                                 uint64_t seed, uint64_t id_base, bool fixed_down)
+                                                 uint64_t seed, uint64_t id_base, uint32_t flags)
 {
     __shared__ BeamShared<PASSES> sh;
     const size_t g = blockIdx.x;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
     GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     while (st.t < max_moves && st.alive) {
         const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t), ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
-        const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
+        const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
         game_apply(st, step_board(st.b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u)), d.expanded);
     }
     if (threadIdx.x == 0) game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
@@ -576,7 +578,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 template <int PASSES>
 __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t *reg_list, SpecSlot *slots, uint32_t n_games,
                             int width, int depth, uint32_t early_thr, uint32_t mid_thr, uint64_t seed, uint64_t id_base,
-                            bool fixed_down)
+                            uint32_t flags)
 {
     for (;;) {
         uint32_t u = 0;
@@ -604,7 +606,7 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
             // (a payload torn by the owner moving on carries the old q, which the owner no longer accepts)
             const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)t);
             const Decision d = beam_decide<PASSES>(sh, root, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, id_base + g,
-                                                   fixed_down);
+                                                   flags);
             if (threadIdx.x == 0) {
                 st_relaxed(&slot->res_action, d.action);
                 st_relaxed(&slot->res_expanded, d.expanded);
@@ -622,14 +624,14 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
                                                       unsigned long long *__restrict__ expanded_out,
                                                       uint8_t *__restrict__ alive_out, int width, int depth, uint32_t early_thr,
                                                       uint32_t mid_thr, int max_moves, uint64_t seed, uint64_t id_base,
-                                                      bool fixed_down, SpecCtl *ctl, uint32_t *reg_list, SpecSlot *slots,
+                                                      uint32_t flags, SpecCtl *ctl, uint32_t *reg_list, SpecSlot *slots,
                                                       uint32_t n_games, int stuck_thr, uint32_t reg_resolved, uint32_t wait_ticks)
 {
     __shared__ BeamShared<PASSES> sh;
     __shared__ uint4 s_req_board[kSpec];
     __shared__ uint32_t s_req_t[kSpec];
     if (blockIdx.x >= n_games) {
-        spec_helper<PASSES>(sh, ctl, reg_list, slots, n_games, width, depth, early_thr, mid_thr, seed, id_base, fixed_down);
+        spec_helper<PASSES>(sh, ctl, reg_list, slots, n_games, width, depth, early_thr, mid_thr, seed, id_base, flags);
         return;
     }
     const uint32_t lane = threadIdx.x;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
         }
         {
             const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t);
-            const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, fixed_down);
+            const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
             const StepOut o = step_board(st.b, d.action, draw);
             game_apply(st, o, d.expanded);
             stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
@@ -732,14 +734,14 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     if (!root_boards || !action_out || !prob_out) { g2048_set_last_error_("g2048_beam_get_action: null pointer"); return G2048_ERR_ARG; }
     if (reinterpret_cast<uintptr_t>(root_boards) & 15u) { g2048_set_last_error_("g2048_beam_get_action: root array must be 16-byte aligned"); return G2048_ERR_ARG; }
     if (width < 1 || width > kMaxWidth) { g2048_set_last_error_("g2048_beam_get_action: width must be in 1..128"); return G2048_ERR_ARG; }
-    if (opts & ~G2048_BEAM_FIXED_DOWN) { g2048_set_last_error_("g2048_beam_get_action: unknown opts"); return G2048_ERR_ARG; }
+    if (opts & ~(G2048_BEAM_FIXED_DOWN | G2048_BEAM_RANK_BY_COUNTING)) { g2048_set_last_error_("g2048_beam_get_action: unknown opts"); return G2048_ERR_ARG; }
     if (n_games > 0x7fffffffu) { g2048_set_last_error_("g2048_beam_get_action: too many games for one launch"); return G2048_ERR_ARG; }
     if (early_threshold < 0 || mid_threshold < 0) { g2048_set_last_error_("g2048_beam_get_action: negative threshold"); return G2048_ERR_ARG; }
     const Keys k = rng_keys(seed, DOM_BEAM, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)n_games);
     const uint4 *roots = static_cast<const uint4 *>(root_boards);
-    const bool fd = (opts & G2048_BEAM_FIXED_DOWN) != 0;
+    const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
     {
 #define G2048_LAUNCH_BEAM(P) hipLaunchKernelGGL(beam_kernel<P>, grid, dim3(64), 0, s, roots, valid_mask_or_null, action_out, prob_out, \
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, \
@@ -775,11 +777,11 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         g2048_set_last_error_("g2048_play_games: board / milestone arrays must be 16-byte aligned"); return G2048_ERR_ARG;
     }
     if (width < 1 || width > kMaxWidth || max_moves < 0 || early_threshold < 0 || mid_threshold < 0 || n_games > 0x7fffffffu ||
-        (opts & ~(G2048_BEAM_FIXED_DOWN | G2048_PLAY_ONE_PHASE))) {
+        (opts & ~(G2048_BEAM_FIXED_DOWN | G2048_PLAY_ONE_PHASE | G2048_BEAM_RANK_BY_COUNTING))) {
         g2048_set_last_error_("g2048_play_games: bad width / max_moves / thresholds / opts / n_games"); return G2048_ERR_ARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool fd = (opts & G2048_BEAM_FIXED_DOWN) != 0;
+    const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
     const int passes = width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8;
 #define G2048_PLAY_ARGS static_cast<uint4 *>(boards_inout), score_inout, moves_out, valid_out, invalid_out, \
                         reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, width, depth, \

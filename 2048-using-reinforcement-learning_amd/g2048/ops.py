@@ -428,6 +428,7 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
                     seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
+                    rank_by_counting=False,
                     out=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
     Returns (actions uint8, probs float32[, expanded int32])."""
@@ -449,7 +450,7 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     head = (roots.data_ptr(), valid_mask.data_ptr() if valid_mask is not None else None, actions.data_ptr(), probs.data_ptr(),
             expanded.data_ptr() if expanded is not None else None, int(width), int(depth), int(early_threshold),
             int(mid_threshold))
-    tail = (L.u64(game_id_base), n, L.BEAM_FIXED_DOWN if fixed_down else 0,
+    tail = (L.u64(game_id_base), n, (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.BEAM_RANK_BY_COUNTING if rank_by_counting else 0),
             L.stream_ptr(dev))
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
@@ -459,7 +460,7 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
 
 
 def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512, mid_threshold=1024, seed=0x2048,
-               game_id_base=0, fixed_down=False, one_phase=False):
+               game_id_base=0, fixed_down=False, one_phase=False, rank_by_counting=False):
     """Every game played to completion in ONE launch (beam get_action -> env step fused per game, reference
     run_evaluation.py:48-69): one wavefront owns a game; helper wavefronts of the same launch search the boards the next
     moves can start from ahead of time, for the games that are left when the chip empties (g2048_beam.hip;
@@ -485,7 +486,8 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
            out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
            out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
            int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
-           (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0),
+           (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0) |
+           (L.BEAM_RANK_BY_COUNTING if rank_by_counting else 0),
            ws.data_ptr() if ws is not None else None, ws_bytes, L.stream_ptr(dev))
     return out
 

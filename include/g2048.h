@@ -82,6 +82,8 @@ enum {
 /* opts of g2048_beam_get_action */
 #define G2048_BEAM_FIXED_DOWN  0x01u   /* use the true DOWN move instead of the reference's rot180 quirk (not parity) */
 
+#define G2048_BEAM_RANK_BY_COUNTING 0x04u /* rank every level by the counting loop instead of the sorting network (same
+                                              decisions; an A/B switch for tests and measurements; also g2048_play_games) */
 /* further opts of g2048_play_games */
 #define G2048_PLAY_ONE_PHASE   0x02u   /* every game on its one wavefront only, no speculative helper wavefronts; the games
                                           are the same either way -- an A/B switch for tests and measurements */

@@ -225,3 +225,19 @@ def test_ranking_network_sorts_64_bit_keys(ops):
             got = [(int(out[w, 2 * i + 1]) << 32) | int(out[w, 2 * i]) for i in range(keep)]
             want = sorted(((int(hi[w, i]) << 32) | int(lo[w, i]) for i in range(m)), reverse=True)[:keep]
             assert got == want, (w, with_extra)
+
+
+@pytest.mark.parametrize("width,depth", [(20, 30), (10, 15), (16, 8), (17, 12), (32, 12), (3, 6)])
+def test_rank_by_counting_switch_same_decisions(ops, oracle, width, depth):
+    """G2048_BEAM_RANK_BY_COUNTING: every level ranked by the counting loop (fast levels in the plain layout, f64 levels in
+    the network's layout -- the path a level takes when two scores are a few ulp apart). Same decisions and expansion
+    counts as the sorting network, and as the oracle."""
+    n = 1536
+    roots = torch.cat([ops.synth_boards(n // 2, seed=21, id_base=0, device=DEV),
+                       ops.synth_boards(n // 2, seed=22, id_base=0, p_empty=0.08, max_code=6, device=DEV)])    # crowded: ties
+    a0, p0, e0 = ops.beam_get_action(roots, width, depth, seed=5, step_index=2, game_id_base=77, want_expanded=True)
+    a1, p1, e1 = ops.beam_get_action(roots, width, depth, seed=5, step_index=2, game_id_base=77, want_expanded=True,
+                                     rank_by_counting=True)
+    assert torch.equal(a0, a1) and torch.equal(p0, p1) and torch.equal(e0, e1)
+    oa, op, oe = oracle.beam_batch(roots[:128].cpu().numpy(), width, depth, seed=5, step_index=2, game_id_base=77)
+    assert np.array_equal(a0[:128].cpu().numpy(), oa) and np.array_equal(e0[:128].cpu().numpy().astype(np.uint32), oe)
