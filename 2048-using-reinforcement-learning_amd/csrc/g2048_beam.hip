@@ -379,8 +379,8 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 // f64 scores as order-preserving unsigned keys (sign bit flipped, negative values complemented; the score
                 // is never -0.0 or NaN), the low seven bits replaced by 127 - generation index: equal scores then sort in
                 // generation order, as Python's stable sort leaves them. Two scores that differ ONLY in those seven bits
-                // would be misordered: if neighbours among the first `width` + 1 agree in everything else, their scores
-                // are read back, and unless they are equal the level goes to the counting loop below instead.
+                // would be misordered: if sorted neighbours agree in everything else, their scores are read back, and unless
+                // they are equal the level goes to the counting loop below instead.
                 Key64 k[PASSES];
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
@@ -392,11 +392,15 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 }
                 const Key64 sorted = top64_desc64(k[0], k[PASSES - 1], with_tail);
                 const uint32_t nhi = (uint32_t)__shfl_down((int)sorted.hi, 1, 64), nlo = (uint32_t)__shfl_down((int)sorted.lo, 1, 64);
-                const bool close = (int)lane < nb && lane < 63u && sorted.hi == nhi && ((sorted.lo ^ nlo) < 128u) && (nhi | nlo) != 0u;
+                // (every run of such neighbours matters, not only those inside the beam: a later member of a run that reaches
+                // into the beam may belong before an earlier one. With the tail merged in only the first 48 places are sorted;
+                // a run that reaches place 47 is not trusted.)
+                const uint32_t last = with_tail ? 46u : 62u;
+                const bool close = lane <= last && sorted.hi == nhi && ((sorted.lo ^ nlo) < 128u) && (nhi | nlo) != 0u;
                 pick = 127u - (sorted.lo & 127u);
                 if (exact && __ballot(close)) {         // equal scores (common: transpositions) or scores a few ulp apart?
                     const double mine = s_score[pick], next = __shfl_down(mine, 1, 64);
-                    exact = __ballot(close && mine != next) == 0ull;
+                    exact = __ballot(close && (mine != next || (with_tail && lane == last))) == 0ull;
                 }
             }
             if (exact) {

@@ -241,3 +241,13 @@ def test_rank_by_counting_switch_same_decisions(ops, oracle, width, depth):
     assert torch.equal(a0, a1) and torch.equal(p0, p1) and torch.equal(e0, e1)
     oa, op, oe = oracle.beam_batch(roots[:128].cpu().numpy(), width, depth, seed=5, step_index=2, game_id_base=77)
     assert np.array_equal(a0[:128].cpu().numpy(), oa) and np.array_equal(e0[:128].cpu().numpy().astype(np.uint32), oe)
+
+
+def test_network_near_tie_run_reaching_into_the_beam(ops, oracle):
+    """Found by comparing complete evaluations: a level of this search has f64 scores that agree in all but their last
+    bits, in a run of sorted neighbours that starts inside the beam and ends outside it. The later member belongs first;
+    only checking neighbours inside the beam missed it (decision 3 / 2043 expansions instead of 2 / 2028)."""
+    root = torch.tensor([[0, 1, 0, 2, 0, 0, 0, 2, 0, 1, 8, 4, 3, 8, 2, 1]], dtype=torch.uint8, device=DEV)
+    a, p, e = ops.beam_get_action(root, 20, 30, seed=2025, step_index=262, game_id_base=472, want_expanded=True)
+    oa, op, oe = oracle.beam_batch(root.cpu().numpy(), 20, 30, seed=2025, step_index=262, game_id_base=472)
+    assert (int(a), int(e)) == (int(oa[0]), int(oe[0])) == (2, 2028)

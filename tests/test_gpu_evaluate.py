@@ -239,3 +239,18 @@ def test_play_games_workspace_entry_points(g2048):
         L.call(dev, L.lib().g2048_play_games_ws, *args(t), small.data_ptr(), need - 64, L.stream_ptr(dev))
     with pytest.raises(RuntimeError, match="workspace"):
         L.call(dev, L.lib().g2048_play_games_ws, *args(t), small.data_ptr() + 16, need, L.stream_ptr(dev))      # misaligned
+
+
+def test_complete_evaluations_network_vs_counting(g2048):
+    """Millions of decisions: 1536 complete games (w=20, d=30) ranked by the sorting networks and by the counting loop end
+    in the same boards, scores and move counts (this comparison is what caught a rare mis-ranking of scores a few ulp
+    apart; tests/test_gpu_beam.py holds that decision)."""
+    from g2048 import ops
+    from g2048.vec import VecGame2048
+    res = []
+    for rbc in (False, True):
+        env = VecGame2048(1536, device=torch.device("cuda"), seed=2025)
+        r = ops.play_games(env.boards, env.scores, 20, 30, 5000, 512, 1024, 2025, 0, False, False, rank_by_counting=rbc)
+        res.append((env.boards.cpu(), env.scores.cpu(), r["moves"].cpu(), r["invalid_moves"].cpu(), r["expanded"].cpu()))
+    assert all(torch.equal(x, y) for x, y in zip(*res))
+    assert int(res[0][2].sum()) > 1_500_000
