@@ -247,10 +247,13 @@ def test_complete_evaluations_network_vs_counting(g2048):
     apart; tests/test_gpu_beam.py holds that decision)."""
     from g2048 import ops
     from g2048.vec import VecGame2048
-    res = []
-    for rbc in (False, True):
-        env = VecGame2048(1536, device=torch.device("cuda"), seed=2025)
-        r = ops.play_games(env.boards, env.scores, 20, 30, 5000, 512, 1024, 2025, 0, False, False, rank_by_counting=rbc)
-        res.append((env.boards.cpu(), env.scores.cpu(), r["moves"].cpu(), r["invalid_moves"].cpu(), r["expanded"].cpu()))
-    assert all(torch.equal(x, y) for x, y in zip(*res))
-    assert int(res[0][2].sum()) > 1_500_000
+    total = 0
+    for n, w, d in ((1536, 20, 30), (1024, 12, 10), (512, 32, 8)):        # two passes with a tail row / one pass / up to 128 children
+        res = []
+        for rbc in (False, True):
+            env = VecGame2048(n, device=torch.device("cuda"), seed=2025 + w)
+            r = ops.play_games(env.boards, env.scores, w, d, 5000, 512, 1024, 2025 + w, 0, False, False, rank_by_counting=rbc)
+            res.append((env.boards.cpu(), env.scores.cpu(), r["moves"].cpu(), r["invalid_moves"].cpu(), r["expanded"].cpu()))
+        assert all(torch.equal(x, y) for x, y in zip(*res)), (n, w, d)
+        total += int(res[0][2].sum())
+    assert total > 2_500_000
