@@ -257,3 +257,14 @@ def test_complete_evaluations_network_vs_counting(g2048):
         assert all(torch.equal(x, y) for x, y in zip(*res)), (n, w, d)
         total += int(res[0][2].sum())
     assert total > 2_500_000
+
+
+def test_reference_configuration_vs_oracle_400_moves(g2048, oracle):
+    """The reference's evaluation configuration itself (width 20, depth 30) against the oracle playing game by game: 24
+    games, the first 400 moves of each (about ten thousand decisions through both sorting networks and the helpers)."""
+    n, w, d, cap, seed = 24, 20, 30, 400, 2025
+    res = g2048.evaluate_beam_search(n, w, d, seed=seed, max_moves=cap, game_id_base=460)
+    for g in range(n):
+        ref = oracle_game(oracle, seed, 460 + g, w, d, cap)
+        assert res["scores"][g] == ref["score"] and res["moves"][g] == ref["moves"], g
+        assert res["invalid_moves"][g] == ref["invalid"] and np.array_equal(res["final_boards"][g], ref["board"]), g
