@@ -268,3 +268,22 @@ def test_reference_configuration_vs_oracle_400_moves(g2048, oracle):
         ref = oracle_game(oracle, seed, 460 + g, w, d, cap)
         assert res["scores"][g] == ref["score"] and res["moves"][g] == ref["moves"], g
         assert res["invalid_moves"][g] == ref["invalid"] and np.array_equal(res["final_boards"][g], ref["board"]), g
+
+
+def test_complete_games_vs_oracle_reference_configuration(g2048):
+    """96 complete games at width 20 / depth 30 / 5000-move cap against the oracle playing them one by one on the host cores
+    (16 worker processes that never touch the GPU; tools/oracle_full_games.py ran 2048 games the same way in round 2)."""
+    import os
+    import sys
+    from multiprocessing import get_context
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import oracle_full_games as T
+    n = 96
+    with get_context("spawn").Pool(16) as pool:
+        job = pool.map_async(T.oracle_game, range(n), chunksize=1)
+        res = g2048.evaluate_beam_search(n, T.W, T.D, seed=T.SEED, max_moves=T.CAP, game_id_base=0)
+        ref = job.get(timeout=280)
+    for gid, score, moves, invalid, board in ref:
+        assert res["scores"][gid] == score and res["moves"][gid] == moves and res["invalid_moves"][gid] == invalid, gid
+        assert [int(x) for x in res["final_boards"][gid].reshape(-1)] == board, gid
