@@ -22,6 +22,7 @@ using namespace g2048;
 namespace {
 
 constexpr int kMaxWidth = G2048_BEAM_MAX_WIDTH;
+constexpr size_t kOrderMinGames = 4096, kOrderMaxGames = 1u << 20;      // batches that get the balanced block order (at 2048 it costs more than it gains)
 
 __device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
 {
@@ -462,16 +463,90 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     return d;
 }
 
+// Blocks b, b + 1024, b + 2048, ... of a one-wavefront-per-block launch share a SIMD on MI355X (256 CUs x 4 SIMDs; measured,
+// tools/ubench/placement.hip), and a launch lasts as long as its most loaded SIMD: with the games in caller order the
+// heaviest SIMD of the benchmark batch carries 17 % more children than the mean. A decision's cost is its depth, which
+// takes one of three values fixed by the root's empty cells (beam_decide :96-106); order[b] = the game block b searches:
+// the games sorted by that class, deepest first, dealt to the SIMDs in rows of 1024 that alternate direction, so that every
+// SIMD gets deep and shallow searches (launch 145 -> 128 us when the order is free, profiles/r02_beam_balance.txt).
+// Deepest-first is also the order that keeps the tail short when the batch is larger than the chip holds at once.
+// One block; a counting sort whose per-class counts are wave ballots (two LDS atomics per wavefront and class in all).
+// Which game a block takes never changes a result.
+__device__ __forceinline__ uint32_t depth_class(const uint4 &rv)         // 0 deepest search .. 2 shallowest
+{
+    const uint32_t root_empty = count_empty(Board{{rv.x, rv.y, rv.z, rv.w}});
+    return root_empty >= 10u ? 2u : root_empty <= 4u ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(1024) void beam_order_kernel(const uint4 *__restrict__ roots, uint32_t *__restrict__ order, uint32_t n,
+                                                         int depth)
+{
+    __shared__ uint32_t s_count[3], s_cursor[3];
+    constexpr int kHeld = 8;                                 // classes of the first 8192 games stay in registers
+    // cost order of the classes: depth for 5..9 empty cells, min(depth + 5, 25) for <= 4, min(depth - 5, 10) for >= 10
+    const int d0 = depth, d1 = min(depth + 5, 25), d2 = min(depth - 5, 10);
+    // rank of each class when sorted by cost, heaviest first (ties keep class order)
+    const uint32_t r0 = (d1 > d0 ? 1u : 0u) + (d2 > d0 ? 1u : 0u), r1 = (d0 >= d1 ? 1u : 0u) + (d2 > d1 ? 1u : 0u);
+    const uint32_t r2 = (d0 >= d2 ? 1u : 0u) + (d1 >= d2 ? 1u : 0u);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < 3) { s_count[threadIdx.x] = 0u; s_cursor[threadIdx.x] = 0u; }
+    uint32_t held[kHeld];
+#pragma unroll
+    for (int k = 0; k < kHeld; ++k) {                        // independent loads: one memory round trip
+        const uint32_t i = (uint32_t)k * 1024u + threadIdx.x;
+        held[k] = i < n ? depth_class(roots[i]) : 3u;
+    }
+    // per-wavefront counts of the three classes, by ballots
+    uint32_t wc0 = 0, wc1 = 0, wc2 = 0;
+    auto tally = [&](uint32_t cls) {
+        wc0 += (uint32_t)__popcll(__ballot(cls == 0u)); wc1 += (uint32_t)__popcll(__ballot(cls == 1u));
+        wc2 += (uint32_t)__popcll(__ballot(cls == 2u));
+    };
+#pragma unroll
+    for (int k = 0; k < kHeld; ++k) if ((uint32_t)k * 1024u < n) tally(held[k]);
+    for (uint32_t i0 = kHeld * 1024u; i0 < n; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        tally(i < n ? depth_class(roots[i]) : 3u);
+    }
+    __syncthreads();
+    const uint32_t mine = lane == 0 ? wc0 : lane == 1 ? wc1 : wc2;
+    if (lane < 3) atomicAdd(&s_count[lane], mine);
+    __syncthreads();
+    // first rank of each class = the games in heavier classes; this wavefront's range inside each class
+    const uint32_t c0 = s_count[0], c1 = s_count[1], c2 = s_count[2];
+    const uint32_t start0 = (r1 < r0 ? c1 : 0u) + (r2 < r0 ? c2 : 0u), start1 = (r0 < r1 ? c0 : 0u) + (r2 < r1 ? c2 : 0u);
+    const uint32_t start2 = (r0 < r2 ? c0 : 0u) + (r1 < r2 ? c1 : 0u);
+    uint32_t base = 0u;
+    if (lane < 3) base = atomicAdd(&s_cursor[lane], mine);
+    uint32_t at0 = start0 + (uint32_t)__builtin_amdgcn_readlane((int)base, 0), at1 = start1 + (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
+    uint32_t at2 = start2 + (uint32_t)__builtin_amdgcn_readlane((int)base, 2);
+    const uint32_t rows = (n + 1023u) >> 10;
+    auto place = [&](uint32_t i, uint32_t cls) {
+        const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+        const uint32_t r = cls == 0u ? at0 + prefix_count(m0) : cls == 1u ? at1 + prefix_count(m1) : at2 + prefix_count(m2);
+        at0 += (uint32_t)__popcll(m0); at1 += (uint32_t)__popcll(m1); at2 += (uint32_t)__popcll(m2);
+        const uint32_t row = r >> 10, q = r & 1023u, len = row + 1u == rows ? n - (row << 10) : 1024u;
+        if (cls < 3u) order[(row << 10) + ((row & 1u) ? len - 1u - q : q)] = i;
+    };
+#pragma unroll
+    for (int k = 0; k < kHeld; ++k) if ((uint32_t)k * 1024u < n) place((uint32_t)k * 1024u + threadIdx.x, held[k]);
+    for (uint32_t i0 = kHeld * 1024u; i0 < n; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        place(i, i < n ? depth_class(roots[i]) : 3u);
+    }
+}
+
 template <int PASSES>
 __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ roots, const uint8_t *__restrict__ mask_in,
                                                  uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
                                                  uint32_t *__restrict__ expanded_out, int width, int depth,
                                                  uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
-                                                 uint64_t id_base, uint32_t flags, const uint32_t *__restrict__ keyblock)
+                                                 uint64_t id_base, uint32_t flags, const uint32_t *__restrict__ keyblock,
+                                                 const uint32_t *__restrict__ order)
 {
     if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
     __shared__ BeamShared<PASSES> sh;
-    const size_t g = blockIdx.x;
+    const size_t g = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
     const uint4 rv = roots[g];
     const Board root = {{rv.x, rv.y, rv.z, rv.w}};
     const Decision d = beam_decide<PASSES>(sh, root, mask_in ? (int)(mask_in[g] & 15u) : -1, width, depth, early_thr, mid_thr,
@@ -732,7 +807,8 @@ void g2048_set_last_error_(const char *msg);
 static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
                      float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                      int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
-                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, const uint32_t *keyblock)
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, const uint32_t *keyblock,
+                     uint32_t *order_ws = nullptr)
 {
     if (n_games == 0) return G2048_OK;
     if (!root_boards || !action_out || !prob_out) { g2048_set_last_error_("g2048_beam_get_action: null pointer"); return G2048_ERR_ARG; }
@@ -746,10 +822,16 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     const dim3 grid((unsigned)n_games);
     const uint4 *roots = static_cast<const uint4 *>(root_boards);
     const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
+    // with scratch for it, and a batch of at least four searches per SIMD, the blocks take the games in a depth-balanced order
+    uint32_t *order = nullptr;
+    if (order_ws && n_games >= kOrderMinGames && n_games <= kOrderMaxGames) {
+        order = order_ws;
+        hipLaunchKernelGGL(beam_order_kernel, dim3(1), dim3(1024), 0, s, roots, order, (uint32_t)n_games, depth);
+    }
     {
 #define G2048_LAUNCH_BEAM(P) hipLaunchKernelGGL(beam_kernel<P>, grid, dim3(64), 0, s, roots, valid_mask_or_null, action_out, prob_out, \
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, \
-                           k.k0, k.k1, game_id_base, fd, keyblock)
+                           k.k0, k.k1, game_id_base, fd, keyblock, order)
         if (width <= 16) G2048_LAUNCH_BEAM(1);
         else if (width <= 32) G2048_LAUNCH_BEAM(2);
         else if (width <= 64) G2048_LAUNCH_BEAM(4);
@@ -898,6 +980,27 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
 {
     return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
                      mid_threshold, seed, step_index, game_id_base, n_games, opts, stream, nullptr);
+}
+
+size_t g2048_beam_workspace_bytes(size_t n_games)
+{
+    return (n_games >= kOrderMinGames && n_games <= kOrderMaxGames) ? n_games * sizeof(uint32_t) : 0;
+}
+
+int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                             float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                             int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                             uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    const size_t need = g2048_beam_workspace_bytes(n_games);
+    if (workspace && need && (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 3u))) {
+        g2048_set_last_error_("g2048_beam_get_action_ws: workspace smaller than g2048_beam_workspace_bytes(n_games) or misaligned");
+        return G2048_ERR_ARG;
+    }
+    return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
+                     mid_threshold, seed, step_index, game_id_base, n_games, opts, stream, nullptr,
+                     need ? static_cast<uint32_t *>(workspace) : nullptr);
 }
 
 int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,

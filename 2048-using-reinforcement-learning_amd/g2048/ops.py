@@ -426,12 +426,16 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
     return out
 
 
+_BEAM_WS = {}
+
+
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
                     seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
-                    rank_by_counting=False,
+                    rank_by_counting=False, balanced_order=True,
                     out=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
-    Returns (actions uint8, probs float32[, expanded int32])."""
+    Returns (actions uint8, probs float32[, expanded int32]). balanced_order: from 4096 roots on, let the blocks take the
+    games in a depth-balanced order (same results, shorter launch; needs 4 bytes of scratch per game, kept per stream)."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
     n = roots.shape[0]
     if not (1 <= int(width) <= L.BEAM_MAX_WIDTH):
@@ -455,7 +459,17 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
     else:
-        L.call(dev, L.lib().g2048_beam_get_action, *head, L.u64(seed), L.u64(step_index), *tail)
+        # scratch for the depth-balanced block order (large batches): caller-owned like every other buffer; one tensor per
+        # (device, stream), reused by later calls, which that stream orders
+        need = 0 if not balanced_order else int(L.lib().g2048_beam_workspace_bytes(n))
+        ws = None
+        if need:
+            key = (dev.index, tail[-1])
+            ws = _BEAM_WS.get(key)
+            if ws is None or ws.numel() < need:
+                ws = _BEAM_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
+               ws.data_ptr() if ws is not None else None, need, tail[-1])
     return (actions, probs, expanded) if (want_expanded or (out is not None and expanded is not None)) else (actions, probs)
 
 

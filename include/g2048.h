@@ -130,6 +130,15 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
                           int width, int depth, int early_threshold, int mid_threshold,
                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
                           uint32_t opts, void *stream);
+/* The same with g2048_beam_workspace_bytes(n_games) bytes of caller-provided device scratch: from 4096 games per
+ * call on, the blocks then take the games in a depth-balanced order (deep and shallow searches mixed on every SIMD) -- same
+ * results, a shorter launch. workspace NULL, or a batch for which the query returns 0: exactly g2048_beam_get_action. */
+size_t g2048_beam_workspace_bytes(size_t n_games);
+int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                             float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                             int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                             uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* Per-move bookkeeping of the reference's evaluation loops (evaluate_beam_search.py:42-64, run_evaluation.py:56-69)
  * for n games after a g2048_step: for games still alive, milestone_move_inout[i][k] (k = 0..7 for tiles 64..8192,

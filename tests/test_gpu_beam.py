@@ -251,3 +251,26 @@ def test_network_near_tie_run_reaching_into_the_beam(ops, oracle):
     a, p, e = ops.beam_get_action(root, 20, 30, seed=2025, step_index=262, game_id_base=472, want_expanded=True)
     oa, op, oe = oracle.beam_batch(root.cpu().numpy(), 20, 30, seed=2025, step_index=262, game_id_base=472)
     assert (int(a), int(e)) == (int(oa[0]), int(oe[0])) == (2, 2028)
+
+
+@pytest.mark.parametrize("n", [4096, 5000, 9300])
+def test_balanced_block_order_is_only_an_order(ops, n):
+    """From 4096 games on (and with scratch) the blocks take their games in a depth-balanced order (beam_order_kernel: counting
+    sort by the search depth the root's empty cells imply, dealt to the SIMDs in alternating rows, partial last row included).
+    Same decisions as the caller's order, and the workspace entry point checks its scratch."""
+    from g2048 import _lib as L
+    roots = torch.cat([ops.synth_boards(n // 3, seed=5, id_base=0, device=DEV),
+                       ops.synth_boards(n // 3, seed=6, id_base=0, p_empty=0.7, max_code=9, device=DEV),
+                       ops.synth_boards(n - 2 * (n // 3), seed=7, id_base=0, p_empty=0.1, device=DEV)])
+    roots = roots[torch.randperm(n, generator=torch.Generator().manual_seed(n)).to(DEV)].contiguous()
+    for depth in (6, 30):                      # depth - 5 < 10 and > 10: the cost order of the three classes differs
+        a, p, e = ops.beam_get_action(roots, 20, depth, seed=77, step_index=3, game_id_base=1000, want_expanded=True)
+        a1, p1, e1 = ops.beam_get_action(roots, 20, depth, seed=77, step_index=3, game_id_base=1000, want_expanded=True,
+                                         balanced_order=False)
+        assert torch.equal(a, a1) and torch.equal(p, p1) and torch.equal(e, e1), depth
+    need = int(L.lib().g2048_beam_workspace_bytes(n))
+    assert need == 4 * n and int(L.lib().g2048_beam_workspace_bytes(100)) == 0
+    small = torch.empty(need - 4, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="workspace"):
+        L.call(roots.device, L.lib().g2048_beam_get_action_ws, roots.data_ptr(), None, a.data_ptr(), p.data_ptr(), None, 20, 6, 512,
+               1024, L.u64(1), L.u64(0), L.u64(0), n, 0, small.data_ptr(), need - 4, L.stream_ptr(roots.device))

@@ -12,8 +12,9 @@ dev = torch.device("cuda")
 import bench
 bench.torch = torch
 roots = bench.beam_roots(ops, n, 0, dev)
+BAL = os.environ.get("NO_BALANCE") is None
 for w in range(3):
-    ops.beam_get_action(roots, 20, 30, seed=SEED, step_index=w, want_expanded=True)
+    ops.beam_get_action(roots, 20, 30, seed=SEED, step_index=w, want_expanded=True, balanced_order=BAL)
 torch.cuda.synchronize()
 best = 0
 for rep in range(3):
@@ -21,10 +22,10 @@ for rep in range(3):
     outs = []
     e0.record()
     for k in range(20):
-        outs.append(ops.beam_get_action(roots, 20, 30, seed=SEED, step_index=10 + k, want_expanded=True)[2])
+        outs.append(ops.beam_get_action(roots, 20, 30, seed=SEED, step_index=10 + k, want_expanded=True, balanced_order=BAL)[2])
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3
     best = max(best, torch.stack(outs).sum().item() / sec)
     us = sec / 20 * 1e6
-print("%s: %d games %.3e expansions/s (%.1f us per call)" % (os.path.basename(os.environ.get("G2048_LIB", "libg2048_hip.so")), n, best, us))
+print(("balanced " if BAL else "caller order ") + "%s: %d games %.3e expansions/s (%.1f us per call)" % (os.path.basename(os.environ.get("G2048_LIB", "libg2048_hip.so")), n, best, us))
