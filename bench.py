@@ -421,7 +421,9 @@ def main():
                           "value": total_exp / bsec, "unit": "expansions/s",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
-                          "kernel": "beam_kernel<2> (one wavefront per game, two 64-child passes per level)"}
+                          "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
+                                    "a bitonic network over the lanes; a 4.5 us beam_order_kernel deals the games to the SIMDs by depth "
+                                    "first -- its time is inside ms_per_batch_decision)"}
         # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
         # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
         # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
