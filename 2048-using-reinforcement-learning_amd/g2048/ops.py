@@ -460,8 +460,9 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
     else:
         # scratch for the depth-balanced block order (large batches): caller-owned like every other buffer; one tensor per
-        # (device, stream), reused by later calls, which that stream orders
-        need = 0 if not balanced_order else int(L.lib().g2048_beam_workspace_bytes(n))
+        # (device, stream), reused by later calls, which that stream orders (not while the stream is being captured: the
+        # cached tensor must not come from a graph's private pool)
+        need = 0 if (not balanced_order or torch.cuda.is_current_stream_capturing()) else int(L.lib().g2048_beam_workspace_bytes(n))
         ws = None
         if need:
             key = (dev.index, tail[-1])
