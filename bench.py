@@ -317,10 +317,12 @@ def main():
     # ---- roofline: algorithmic bytes per launch / average launch duration over the timed region ----
     achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
     traffic = traffic_src = None
+    pmc_extra = {}
     pmc = os.path.join(REPO, "profiles", "pmc_step.json")     # HBM bytes per launch from the rocprofv3 PMC passes
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
         traffic = pj.get("hbm_bytes_per_launch")
+        pmc_extra = pj
         traffic_src = "recorded rocprofv3 PMC passes (%s), not an observation of this run" % pj.get("source", "profiles/pmc_step.json")
 
     result = {
@@ -369,6 +371,9 @@ def main():
                                          "unit": "GB/s", "frac": n * STEP_BYTES_F64 / us / 1e3 / HBM_PEAK_GBS, "kernel_us": us,
                                          "kernel": "step_kernel<true,false,1,256>", "bytes_per_board": STEP_BYTES_F64,
                                          "board_steps_per_s": n / us * 1e6,
+                                         "traffic": (pmc_extra.get("f64_reward_mode") or {}).get("hbm_bytes_per_launch"),
+                                         "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
+                                                           % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
                                          "note": "bit-exact parity mode: reward written as f64 (50 B per board-step)"}
         del reward64, g64
         nb = BIG_BOARDS
@@ -390,6 +395,9 @@ def main():
         result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
                                            "kernel_us": us, "boards_per_launch": nb,
+                                           "traffic": (pmc_extra.get("hbm_resident_leg") or {}).get("hbm_bytes_per_launch"),
+                                           "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
+                                                             % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
                                            "kernel": "step_kernel<false,false,2,256> (two boards per lane from 4 Mi boards per launch on)",
                                            "algorithmic_bytes_per_launch": nb * STEP_BYTES_F32,
                                            "board_steps_per_s": nb / us * 1e6,
