@@ -268,6 +268,10 @@ def test_balanced_block_order_is_only_an_order(ops, n):
         a1, p1, e1 = ops.beam_get_action(roots, 20, depth, seed=77, step_index=3, game_id_base=1000, want_expanded=True,
                                          balanced_order=False)
         assert torch.equal(a, a1) and torch.equal(p, p1) and torch.equal(e, e1), depth
+    mask = torch.randint(0, 16, (n,), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).to(DEV)      # caller masks too
+    am, pm = ops.beam_get_action(roots, 20, 6, mask, seed=78, step_index=4, game_id_base=5)
+    am1, pm1 = ops.beam_get_action(roots, 20, 6, mask, seed=78, step_index=4, game_id_base=5, balanced_order=False)
+    assert torch.equal(am, am1) and torch.equal(pm, pm1)
     need = int(L.lib().g2048_beam_workspace_bytes(n))
     assert need == 4 * n and int(L.lib().g2048_beam_workspace_bytes(100)) == 0
     small = torch.empty(need - 4, dtype=torch.uint8, device=DEV)
