@@ -263,6 +263,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
 
     int nb = 0;                    // current beam size
     uint32_t draws = 0, expanded = 0;
+    // stage A's lane 2p + axis keeps its axis for the whole search: the direction network's selector words (rows -> lines,
+    // forward lines -> rows, reversed lines -> rows with the agent's DOWN quirk folded in) are loop-invariant registers
+    AxisSel asel = axis_sel((lane & 1u) != 0u, fixed_down);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(asel.in[k]), "+v"(asel.fwd[k]), "+v"(asel.rev[k]));   // (not re-derived per level)
 
     for (int level = 0; level == 0 || level < actual_depth; ++level) {
         const bool fast = level == 0 || level > 3;             // :122, :139
@@ -285,12 +290,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 ra_f = ra_r = s_root[par];
             }
             Board cf, cr;
-            move_axis(P, vertical, cf, cr);                                      // :115 / :152
-            if (!fixed_down) {                                                   // the agent's DOWN = rot180(true DOWN)
-                const Board q = rot180(cr);
-                cr.w[0] = vertical ? q.w[0] : cr.w[0]; cr.w[1] = vertical ? q.w[1] : cr.w[1];
-                cr.w[2] = vertical ? q.w[2] : cr.w[2]; cr.w[3] = vertical ? q.w[3] : cr.w[3];
-            }
+            move_axis_sel(P, asel, cf, cr);                                      // :115 / :152 (the agent's DOWN = rot180(true DOWN))
             const bool vf = en_f && !same(cf, P), vr = en_r && !same(cr, P);
             const unsigned long long bf = __ballot(vf), br = __ballot(vr);
             const uint32_t before = total_valid + prefix_count(bf) + prefix_count(br);    // valid children generated earlier

@@ -245,6 +245,43 @@ G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev)
     move_axis(b, vertical, fwd, rev, mf, mr);
 }
 
+// The same pair of moves through the direction network (round 3): a lane's axis never changes during a search, so its
+// three selector sets -- rows -> lines, forward lines -> rows, reversed lines -> rows -- are loop-invariant per-lane data
+// and both moves cost 24 v_perm in all: no transpose whose result half the lanes discard, no v_cndmask (move_axis above:
+// 28 v_perm + 16 v_cndmask with the agent's DOWN quirk applied by the caller). The reversed slide runs on the line order
+// {3,2,1,0}; its results R[k] are position 3-k, which is exactly the line order RIGHT's output selectors expect
+// (G2048_DIR_TABLE_INIT: RIGHT's input net yields LEFT's lines reversed). For the vertical axis the reverse-output
+// selectors also carry BeamSearchAgent._make_move's DOWN quirk (agents/beam_search_agent.py:209-210 vs :251-253, result =
+// rot180(true DOWN)): rot180 of the rows {R3,R2,R1,R0} is the byte reversal of {R0,R1,R2,R3} -- identity word routing in
+// stage 1, byte reversal in stage 2; `fixed_down` routes the words back in reversed order instead (DOWN's table entry).
+struct AxisSel { uint32_t in[4], fwd[4], rev[4]; };
+
+G2048_HD AxisSel axis_sel(bool vertical, bool fixed_down)
+{
+    AxisSel s;
+    const uint32_t lo = 0x03020100u, hi = 0x07060504u;
+    // horizontal: LEFT's rows <-> lines transpose (an involution), RIGHT's lines -> rows
+    s.in[0] = vertical ? lo : 0x05040100u; s.in[1] = vertical ? hi : 0x07060302u;
+    s.in[2] = vertical ? lo : 0x06020400u; s.in[3] = vertical ? hi : 0x07030501u;
+    s.fwd[0] = s.in[0]; s.fwd[1] = s.in[1]; s.fwd[2] = s.in[2]; s.fwd[3] = s.in[3];
+    s.rev[0] = vertical ? (fixed_down ? hi : lo) : 0x05040100u;
+    s.rev[1] = vertical ? (fixed_down ? lo : hi) : 0x07060302u;
+    s.rev[2] = vertical ? (fixed_down ? hi : 0x00010203u) : 0x00040206u;
+    s.rev[3] = vertical ? (fixed_down ? lo : 0x04050607u) : 0x01050307u;
+    return s;
+}
+
+G2048_HD void move_axis_sel(const Board &b, const AxisSel &s, Board &fwd, Board &rev)
+{
+    uint32_t F[4], mf, mr;
+    dir_net(b.w, s.in[0], s.in[1], s.in[2], s.in[3], F);
+    uint32_t R[4] = {F[3], F[2], F[1], F[0]};
+    (void)slide_lines(F, mf);
+    (void)slide_lines(R, mr);
+    dir_net(F, s.fwd[0], s.fwd[1], s.fwd[2], s.fwd[3], fwd.w);
+    dir_net(R, s.rev[0], s.rev[1], s.rev[2], s.rev[3], rev.w);
+}
+
 // BeamSearchAgent._make_move (agents/beam_search_agent.py:194-258): LEFT/UP/RIGHT
 // as the env; DOWN returns rot180 of the true result because the post-transform
 // (:252-253) is not the inverse of the pre-transform (:210). `fixed_down` turns

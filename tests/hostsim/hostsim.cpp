@@ -45,6 +45,15 @@ void hs_move(const uint8_t *in, const uint8_t *actions, int agent, uint8_t *out,
             const Board o1 = move_env(b, actions[i] & 3u, g, m1), o2 = move_env_sel(b, dir_sel(actions[i]), g2, m2);
             if (!same(o1, o2) || g2 != g || m1 != m2) o.w[0] = 0xffffffffu;
         }
+        if (agent) {        // the beam kernel's axis-pair move through loop-invariant selectors must give the same boards,
+            Board f, r;     // with the DOWN quirk (move_agent) and without it (the env's move)
+            move_axis_sel(b, axis_sel((actions[i] & 1u) != 0u, false), f, r);
+            if (!same((actions[i] & 2u) ? r : f, o)) o.w[0] = 0xffffffffu;
+            uint32_t g3;
+            const Board e = move_env(b, actions[i] & 3u, g3);
+            move_axis_sel(b, axis_sel((actions[i] & 1u) != 0u, true), f, r);
+            if (!same((actions[i] & 2u) ? r : f, e)) o.w[0] = 0xffffffffu;
+        }
         st(out + 16 * i, o); gain[i] = g; valid[i] = !same(o, b);
     }
 }
