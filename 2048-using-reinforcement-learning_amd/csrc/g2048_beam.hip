@@ -57,26 +57,49 @@ __device__ __forceinline__ uint32_t pick_by_mask(uint32_t if0, uint32_t if1, uin
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_of(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 
+// One compare-exchange step in two vector instructions (round 3; three to five before: v_max_dpp + v_min_dpp + v_cndmask): the
+// compare reads the partner's key through its DPP operand, the scalar unit turns "partner > mine" into "keep mine" with the
+// step's keep-the-larger lane mask, and the select reads the partner's key through DPP again:
+//     vcc = borrow of dpp(key) - key  (= mine > partner's) ;  vcc ^= ~keep_max ;  key = vcc ? key : dpp(key)
+// gfx950 has no DPP form of v_cmp (VOPC), so the compare is the carry-out of a VOP2 subtraction whose difference is thrown
+// away. The instructions are written out because the select must be the VOP2 form to take a DPP operand; the s_nop covers the
+// "VALU writes a VGPR, a DPP operand reads it" wait states for whatever produced `key` just before.
+#define G2048_CX_DPP(CTRL)                                                                             \
+    asm("s_nop 1\n\t"                                                                                  \
+        "v_sub_co_u32_dpp %0, vcc, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "s_xor_b64 vcc, vcc, %2\n\t"                                                                    \
+        "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                         \
+        : "=&v"(out) : "v"(src), "s"(~keep_max) : "vcc")
+
 template <int K, int J>
 __device__ __forceinline__ uint32_t cx_step(uint32_t key)
 {
     constexpr uint64_t keep_max = cx_mask(K, J);
-    uint32_t hi, lo;
-    if (J == 1) { hi = max(dpp_of<0xB1>(key), key); lo = min(dpp_of<0xB1>(key), key); }              // quad_perm [1,0,3,2]
-    else if (J == 2) { hi = max(dpp_of<0x4E>(key), key); lo = min(dpp_of<0x4E>(key), key); }         // quad_perm [2,3,0,1]
-    else if (J == 4) {                                                                               // e ^ 3, then e ^ 7
-        const uint32_t r = dpp_of<0x1B>(key);                                                        // quad_perm [3,2,1,0]
-        hi = max(dpp_of<0x141>(r), key); lo = min(dpp_of<0x141>(r), key);                            // row_half_mirror
-    } else if (J == 8) { hi = max(dpp_of<0x128>(key), key); lo = min(dpp_of<0x128>(key), key); }     // row_ror:8
-    else if (J == 16) {                          // odd rows of one copy <-> even rows of the other: both lanes of a pair see both keys
-        const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false);
-        hi = max(r[0], r[1]); lo = min(r[0], r[1]);
-    } else {
-        const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false);
-        hi = max(r[0], r[1]); lo = min(r[0], r[1]);
+    if (J == 16 || J == 32) {                    // odd rows of one copy <-> even rows of the other: both lanes of a pair see both keys
+        uint32_t a, b;
+        asm("s_nop 1" : "+v"(key));              // (a written-out step may have produced key: wait states before the lane swap reads it)
+        if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); a = r[0]; b = r[1]; }
+        else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); a = r[0]; b = r[1]; }
+        return pick_by_mask(b, a, ~(__ballot(a > b) ^ keep_max));       // the larger one where keep_max, else the smaller
     }
-    return pick_by_mask(lo, hi, keep_max);
+    uint32_t out, src = key;
+    if (J == 1) G2048_CX_DPP("quad_perm:[1,0,3,2]");
+    else if (J == 2) G2048_CX_DPP("quad_perm:[2,3,0,1]");
+    else if (J == 8) G2048_CX_DPP("row_ror:8");
+    else {
+        // J == 4: e ^ 3 (quad_perm [3,2,1,0]) into a scratch register, then e ^ 7 (row_half_mirror) on the operands = e ^ 4
+        uint32_t tmp;
+        asm("s_nop 1\n\t"
+            "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_sub_co_u32_dpp %0, vcc, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_xor_b64 vcc, vcc, %3\n\t"
+            "v_cndmask_b32_dpp %0, %1, %2, vcc row_half_mirror row_mask:0xf bank_mask:0xf"
+            : "=&v"(out), "=&v"(tmp) : "v"(src), "s"(~keep_max) : "vcc");
+    }
+    return out;
 }
+#undef G2048_CX_DPP
 
 // stages k = 2 .. KMAX of the 64-lane descending network: KMAX = 64 sorts the wavefront's keys, descending by lane; KMAX = 16
 // leaves every 16-lane row sorted, rows 0 and 2 descending, rows 1 and 3 ASCENDING
@@ -343,7 +366,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 const unsigned long long bc = __ballot(live && n_moved != 0u);
                 const uint32_t j = draws + prefix_count(bc);
                 draws += (uint32_t)__popcll(bc);
+#ifdef G2048_BEAM_SPAWN_SELECT
                 spawn(c, rng_draw(k0, k1, gid, j));                              // :118 / :155; a no-op on a full board
+#else
+                spawn_prefix(c, rng_draw(k0, k1, gid, j));                       // :118 / :155; a no-op on a full board
+#endif
                 // :122 / :158-161. What the evaluators need is already known: the empty count (one fewer after a spawn)
                 // and the max code -- a move raises the parent's max by at most one, exactly when some cell now holds
                 // parent max + 1 (two max tiles merged, or a 2/4 spawned onto a board whose max was lower)

@@ -315,7 +315,7 @@ G2048_HD uint32_t valid_mask_env(const Board &b)
         const uint32_t z = n ^ B80;
         left |= z & ((n >> 8) | (n >> 16) | (n >> 24));      // empty with a tile at a higher column
         right |= z & ((n << 8) | (n << 16) | (n << 24));     // empty with a tile at a lower column
-        ph |= eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u;
+        ph |= eqnzflag(b.w[r], b.w[r] >> 8);                 // (byte 3 compares with the 0 shifted in: never "equal and non-zero")
     }
     return ((left | ph) ? 1u : 0u) | ((up | pv) ? 2u : 0u) | ((right | ph) ? 4u : 0u) | ((down | pv) ? 8u : 0u);
 }
@@ -508,7 +508,7 @@ G2048_HD double reward_env_from(double r, const Board &cur, const TileStats &st,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t x = cur.w[i], n = i == 0 ? n0 : i == 1 ? n1 : i == 2 ? n2 : n3;
-        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8) & 0x00808080u;
+        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8);                  // (n >> 8 has no flag in byte 3)
         const uint32_t c = popc(h) + ((colcnt >> (8 * i)) & 0xffu);
         r += (double)c * 0.1;
     }
@@ -539,7 +539,7 @@ G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t x = cur.w[i], n = i == 0 ? n0 : i == 1 ? n1 : i == 2 ? n2 : n3;
-        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8) & 0x00808080u;
+        const uint32_t h = geflag(x >> 8, x) & n & (n >> 8);                  // (n >> 8 has no flag in byte 3)
         const uint32_t c = popc(h) + ((colcnt >> (8 * i)) & 0xffu);
         r += (double)c * 0.1;
     }
@@ -743,7 +743,7 @@ G2048_HD uint32_t pair_count(const Board &b)      // adjacent equal non-zero pai
     // byte, so one OR-reduction and one popcount count them all
     uint32_t w = eqnzflag(b.w[0], b.w[1]) | (eqnzflag(b.w[1], b.w[2]) >> 1) | (eqnzflag(b.w[2], b.w[3]) >> 2);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w |= (eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u) >> (3 + r);
+    for (int r = 0; r < 4; ++r) w |= eqnzflag(b.w[r], b.w[r] >> 8) >> (3 + r);       // byte 3 meets the 0 shifted in: no flag there
     return popc(w);
 }
 
@@ -790,7 +790,7 @@ G2048_HD uint32_t merge_potential(const Board &b)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const uint32_t f = eqnzflag(b.w[r], b.w[r] >> 8) & 0x00808080u;
+        const uint32_t f = eqnzflag(b.w[r], b.w[r] >> 8);
         acc = dot4(b.w[r], f >> 7, acc);
     }
     return acc;
@@ -842,7 +842,7 @@ G2048_HD MonoCounts mono_counts(const Board &b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t x = b.w[r], n = r == 0 ? n0 : r == 1 ? n1 : r == 2 ? n2 : n3;
-        const uint32_t both = n & (n >> 8) & 0x00808080u;
+        const uint32_t both = n & (n >> 8);
         m.rle += popc(geflag(x >> 8, x) & both);
         m.rge += popc(geflag(x, x >> 8) & both);
     }

@@ -145,6 +145,61 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     }
 }
 
+// ------------------------------------------------------------- step, T times --
+// T consecutive env steps of every board in ONE launch (random playouts: SURVEY 8d C2 "rollout" variant). Consecutive
+// g2048_step launches re-read and re-write 46 B per board and pay the launch's ramp-up every step; here the board, its score
+// and the direction table stay in registers / LDS for all T steps, the per-step keys of the three RNG domains are derived
+// on the scalar unit from (seed, domain, step index) -- the same keys the host derives for g2048_step -- and only what
+// the caller asks for per step (reward / flags streams) is written. Step t is bit-for-bit g2048_step(step_index0 + t,
+// G2048_STEP_RANDOM_ACTIONS [| G2048_STEP_AUTO_RESET]).
+template <bool REWARD_F64, bool AUTO_RESET, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in, uint4 *boards_out, uint32_t *__restrict__ score,
+                                                          void *__restrict__ reward_stream, uint8_t *__restrict__ flags_stream,
+                                                          uint8_t *__restrict__ flags_last, uint32_t *__restrict__ episodes_out,
+                                                          uint64_t seed, uint64_t step_index0, uint32_t steps, uint64_t id_base,
+                                                          size_t n)
+{
+    __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
+    dir_table_to_lds(s_dir);
+    // per-block scalar bases + a 32-bit lane offset, as in step_kernel; the streams advance by n per step on the scalar unit
+    const size_t block0 = (size_t)blockIdx.x * BLOCK;
+    if (block0 + threadIdx.x >= n) return;
+    const uint32_t j = threadIdx.x;
+    const uint64_t id = id_base + block0 + j;
+    Board cur = load_board(boards_in + block0, j);
+    uint32_t sc = score[block0 + j], flags = 0u, episodes = 0u;
+    float *rw32 = static_cast<float *>(reward_stream) + block0;
+    double *rw64 = static_cast<double *>(reward_stream) + block0;
+    uint8_t *fl = flags_stream + block0;
+    for (uint32_t t = 0; t < steps; ++t) {
+        const uint64_t index = step_index0 + t;                          // uniform: scalar unit
+        const Keys ks = rng_keys(seed, DOM_STEP, index), ka = rng_keys(seed, DOM_SYNTH_ACTION, index);
+        const uint32_t action = rng_draw(ka.k0, ka.k1, id, 0u) >> 30;       // what g2048_synth_actions would write
+        const StepOut o = step_board_sel(cur, dir_sel(s_dir, action), rng_draw(ks.k0, ks.k1, id, 0u));
+        cur = o.board;
+        sc += o.gain;
+        flags = o.flags;
+        if (AUTO_RESET) {
+            if (o.flags & G2048_FLAG_DONE) {
+                const Keys ke = rng_keys(seed, DOM_EPISODE, index);
+                cur = fresh_board(rng_draw(ke.k0, ke.k1, id, 0u), rng_draw(ke.k0, ke.k1, id, 1u));
+                sc = 0u;
+                ++episodes;
+            }
+        }
+        if (reward_stream) {
+            if (REWARD_F64) rw64[j] = o.reward;
+            else rw32[j] = (float)o.reward;
+            rw64 += n; rw32 += n;
+        }
+        if (flags_stream) { fl[j] = (uint8_t)o.flags; fl += n; }
+    }
+    store_board(boards_out + block0, j, cur);
+    score[block0 + j] = sc;
+    flags_last[block0 + j] = (uint8_t)flags;
+    if (episodes_out) episodes_out[block0 + j] = episodes;
+}
+
 // ------------------------------------------------------------------ reset -----
 __global__ __launch_bounds__(kBlock) void reset_kernel(uint4 *__restrict__ boards_out, uint32_t *__restrict__ score_out,
                                                       uint32_t k0, uint32_t k1, uint64_t id_base, size_t n)
@@ -524,6 +579,32 @@ int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_o
     if (!keyblock) return fail(G2048_ERR_ARG, "g2048_step_dyn: null key block");
     return step_impl(boards_in, actions, boards_out, score_inout, reward_out, flags_out, 0, 0, board_id_base, n, opts, stream,
                      keyblock);
+}
+
+int g2048_step_many(const void *boards_in, void *boards_out, uint32_t *score_inout, void *reward_stream_out_or_null,
+                    uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out, uint32_t *episodes_out_or_null, uint64_t seed,
+                    uint64_t step_index0, uint32_t steps, uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards_in || !boards_out || !score_inout || !flags_last_out) return fail(G2048_ERR_ARG, "g2048_step_many: null pointer");
+    if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step_many: board arrays must be 16-byte aligned");
+    const bool f64 = (opts & G2048_STEP_REWARD_F64) != 0u, ar = (opts & G2048_STEP_AUTO_RESET) != 0u;
+    if (!aligned4(score_inout) || (episodes_out_or_null && !aligned4(episodes_out_or_null)) ||
+        (reward_stream_out_or_null && (reinterpret_cast<uintptr_t>(reward_stream_out_or_null) & (f64 ? 7u : 3u))))
+        return fail(G2048_ERR_ARG, "g2048_step_many: score / reward / episode arrays misaligned");
+    if (!(opts & G2048_STEP_RANDOM_ACTIONS)) return fail(G2048_ERR_ARG, "g2048_step_many: the in-kernel policy is G2048_STEP_RANDOM_ACTIONS (set it)");
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS)) return fail(G2048_ERR_ARG, "g2048_step_many: unknown opts 0x%x", opts);
+    if (steps == 0) return fail(G2048_ERR_ARG, "g2048_step_many: steps must be at least 1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define G2048_LAUNCH_MANY(F, A) hipLaunchKernelGGL((step_many_kernel<F, A, kBlock>), dim3(blocks_for(n)), dim3(kBlock), 0, s, \
+                           static_cast<const uint4 *>(boards_in), static_cast<uint4 *>(boards_out), score_inout, reward_stream_out_or_null, \
+                           flags_stream_out_or_null, flags_last_out, episodes_out_or_null, seed, step_index0, steps, board_id_base, n)
+    if (f64 && ar) G2048_LAUNCH_MANY(true, true);
+    else if (f64) G2048_LAUNCH_MANY(true, false);
+    else if (ar) G2048_LAUNCH_MANY(false, true);
+    else G2048_LAUNCH_MANY(false, false);
+#undef G2048_LAUNCH_MANY
+    return check_launch("g2048_step_many");
 }
 
 int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch, uint64_t board_id_base,

@@ -102,6 +102,49 @@ class PreparedStep:
             L.check(rc)
 
 
+def step_many(boards, scores, seed, step_index0, steps, id_base=0, out=None, flags=None, reward_stream=None,
+              flags_stream=None, episodes=None, reward_f64=False, auto_reset=False, want_rewards=False, want_flags=False,
+              want_episodes=False):
+    """`steps` consecutive random-playout steps of every board in ONE launch (g2048_step_many): step t equals
+    `step(boards, None, scores, seed, step_index0 + t, id_base, auto_reset=...)` bit for bit, but the boards stay in registers
+    between the steps. scores is updated in place; `out` may be `boards`. Returns (boards_out, flags_last, reward_stream or
+    None, flags_stream or None, episodes or None); the streams are (steps, n) tensors, allocated when want_* is set."""
+    L.require_device_tensor(boards, torch.uint8, (16,), "boards")
+    n, steps = boards.shape[0], int(steps)
+    if steps < 1:
+        raise ValueError("g2048: steps must be at least 1")
+    _require_scores(scores)
+    if scores.shape[0] != n:
+        raise ValueError("g2048: scores length must equal the number of boards")
+    dev = _dev(boards)
+    if out is None:
+        out = torch.empty_like(boards)
+    if flags is None:
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
+    rdt = torch.float64 if reward_f64 else torch.float32
+    if reward_stream is None and want_rewards:
+        reward_stream = torch.empty((steps, n), dtype=rdt, device=dev)
+    if flags_stream is None and want_flags:
+        flags_stream = torch.empty((steps, n), dtype=torch.uint8, device=dev)
+    if episodes is None and want_episodes:
+        episodes = torch.empty(n, dtype=torch.int32, device=dev)
+    L.require_device_tensor(out, torch.uint8, (16,), "out")
+    L.require_device_tensor(flags, torch.uint8, None, "flags")
+    for t, dt, name in ((reward_stream, rdt, "reward_stream"), (flags_stream, torch.uint8, "flags_stream")):
+        if t is not None:
+            L.require_device_tensor(t, dt, None, name)
+            if tuple(t.shape) != (steps, n):
+                raise ValueError("g2048: %s must have shape (steps, n)" % name)
+    if episodes is not None:
+        L.require_device_tensor(episodes, torch.int32, None, "episodes")
+    opts = L.STEP_RANDOM_ACTIONS | (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0)
+    L.call(dev, L.lib().g2048_step_many, boards.data_ptr(), out.data_ptr(), scores.data_ptr(),
+           None if reward_stream is None else reward_stream.data_ptr(), None if flags_stream is None else flags_stream.data_ptr(),
+           flags.data_ptr(), None if episodes is None else episodes.data_ptr(), L.u64(seed), L.u64(step_index0), steps,
+           L.u64(id_base), n, opts, L.stream_ptr(dev))
+    return out, flags, reward_stream, flags_stream, episodes
+
+
 def reset(n, seed, epoch=0, id_base=0, device="cuda", boards=None, scores=None):
     """Game2048Env.reset for n boards (environment/game_2048.py:29-48). Returns (boards, scores)."""
     dev = torch.device(device) if boards is None else boards.device

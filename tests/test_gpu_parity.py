@@ -459,3 +459,58 @@ def test_obs_f16_bf16(ops, oracle):
         assert got.dtype == dt and bool((got.view(torch.int16) == f32.to(dt).view(torch.int16)).all())
     out = torch.empty((200003, 16), dtype=torch.bfloat16, device=DEV)
     assert ops.obs(b, out=out) is out
+
+
+@pytest.mark.parametrize("steps", [1, 2, 128])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_many_equals_sequential_steps(ops, oracle, steps, auto_reset):
+    """g2048_step_many (boards in registers for T steps, in-kernel random actions) == T sequential g2048_step launches with
+    G2048_STEP_RANDOM_ACTIONS, bit for bit: final boards / scores / last flags, every step's reward (f64 ==) and flags, for a
+    ragged n; and, at the first steps, == the oracle fed the actions synth_actions gives."""
+    n, seed, base, t0 = 100003, 4242, 3 << 34, 7
+    b0, s0 = ops.reset(n, seed, 1, base, device=DEV)
+    if not auto_reset:                      # start near the end of the episodes so that finished boards get stepped too
+        s0.zero_()
+        b0 = ops.synth_boards(n, seed=seed, id_base=base, p_empty=0.05, max_code=6, device=DEV)
+    for f64 in (True, False):
+        b, sc = b0.clone(), s0.clone()
+        rws, fls = [], []
+        for t in range(steps):
+            b, rw, fl = ops.step(b, None, sc, seed, t0 + t, base, reward_f64=f64, auto_reset=auto_reset)
+            rws.append(rw); fls.append(fl)
+        sm = s0.clone()
+        out, flast, rstream, fstream, eps = ops.step_many(b0.clone(), sm, seed, t0, steps, base, reward_f64=f64, auto_reset=auto_reset,
+                                                          want_rewards=True, want_flags=True, want_episodes=True)
+        assert bool((out == b).all()) and bool((sm == sc).all()) and bool((flast == fls[-1]).all())
+        assert np.array_equal(host(rstream), host(torch.stack(rws)), equal_nan=True)
+        assert bool((fstream == torch.stack(fls)).all())
+        done = (torch.stack(fls) & 1).to(torch.int32).sum(0)
+        assert bool((eps == (done if auto_reset else torch.zeros_like(done))).all())
+        # in place, no optional outputs
+        sm2, bi = s0.clone(), b0.clone()
+        out2, fl2, r2, f2, e2 = ops.step_many(bi, sm2, seed, t0, steps, base, out=bi, reward_f64=f64, auto_reset=auto_reset)
+        assert out2 is bi and r2 is None and f2 is None and e2 is None
+        assert bool((bi == b).all()) and bool((sm2 == sc).all()) and bool((fl2 == fls[-1]).all())
+    # the oracle on the same draws (explicit actions), two steps
+    hb, hs = host(b0), host(s0).astype(np.uint32)
+    k = min(steps, 2)
+    for t in range(k):
+        ha = oracle.synth_actions(n, seed=seed, step_index=t0 + t, id_base=base)
+        hb, hs, hr, hf = oracle.step_batch(hb, ha, hs, seed=seed, step_index=t0 + t, id_base=base, opts=1 if auto_reset else 0)
+    sm = s0.clone()
+    out, flast, rstream, _, _ = ops.step_many(b0.clone(), sm, seed, t0, k, base, reward_f64=True, auto_reset=auto_reset, want_rewards=True)
+    assert np.array_equal(host(out), hb) and np.array_equal(host(sm).astype(np.uint32), hs) and np.array_equal(host(flast), hf)
+    assert np.array_equal(host(rstream[k - 1]), hr, equal_nan=True)
+
+
+def test_step_many_argument_checks(ops):
+    b, s = ops.reset(64, 1, 0, 0, device=DEV)
+    from g2048 import _lib as L
+    fl = torch.empty(64, dtype=torch.uint8, device=DEV)
+    rc = L.lib().g2048_step_many(b.data_ptr(), b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 4, 0, 64, 0, None)
+    assert rc == -1 and b"RANDOM_ACTIONS" in L.lib().g2048_last_error()
+    rc = L.lib().g2048_step_many(b.data_ptr(), b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 0, 0, 64, 4, None)
+    assert rc == -1
+    with pytest.raises(ValueError):
+        ops.step_many(b, s, 1, 0, 0)
+    assert L.lib().g2048_step_many(None, None, None, None, None, None, None, 1, 0, 4, 0, 0, 4, None) == 0       # n = 0: a no-op
