@@ -75,6 +75,18 @@ template <int K, int J>
 __device__ __forceinline__ uint32_t cx_step(uint32_t key)
 {
     constexpr uint64_t keep_max = cx_mask(K, J);
+#ifndef G2048_BEAM_CX_SUBCO          // default: v_max_dpp + v_min_dpp + v_cndmask (A/B switch: the two-instruction form below)
+    {
+        uint32_t hi, lo;
+        if (J == 1) { hi = max(dpp_of<0xB1>(key), key); lo = min(dpp_of<0xB1>(key), key); }
+        else if (J == 2) { hi = max(dpp_of<0x4E>(key), key); lo = min(dpp_of<0x4E>(key), key); }
+        else if (J == 4) { const uint32_t r = dpp_of<0x1B>(key); hi = max(dpp_of<0x141>(r), key); lo = min(dpp_of<0x141>(r), key); }
+        else if (J == 8) { hi = max(dpp_of<0x128>(key), key); lo = min(dpp_of<0x128>(key), key); }
+        else if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); hi = max(r[0], r[1]); lo = min(r[0], r[1]); }
+        else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); hi = max(r[0], r[1]); lo = min(r[0], r[1]); }
+        return pick_by_mask(lo, hi, keep_max);
+    }
+#endif
     if (J == 16 || J == 32) {                    // odd rows of one copy <-> even rows of the other: both lanes of a pair see both keys
         uint32_t a, b;
         asm("s_nop 1" : "+v"(key));              // (a written-out step may have produced key: wait states before the lane swap reads it)
@@ -341,6 +353,46 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         // ---- stage B: spawn + score of the compacted children, one per lane and pass (a pass only runs if it has children)
         // Ranking by sorting network (above) for beams up to 32 wide, when the level has 17 .. 80 children (wave-uniform): then
         // the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the network wants their keys.
+#ifndef G2048_BEAM_NO_DUAL
+        // The common level of a width-17..32 search: _fast_evaluate scores and 65..80 children. Both passes -- 64 children, then
+        // the up to 16 more in lanes 48..63 -- the write-back and the sorting network run as ONE straight-line block, so that the
+        // second pass's spawn + score (independent work) fills the issue slots the first pass's dependent chains and the network's
+        // serial compare-exchange steps leave open: with four wavefronts per SIMD (4096 games) the search is bound by each
+        // wavefront's own latency, not by instruction issue (profiles/r03_beam_latency.txt).
+        if (PASSES == 2 && fast && !count_rank && total_valid > 64u && total_valid <= 80u) {
+            const uint32_t ci1 = lane + 16u;
+            const bool live1 = lane >= 48u && ci1 < total_valid;
+            const uint4 cv0 = s_cboard[lane], cv1 = s_cboard[live1 ? ci1 : 0u];
+            const uint32_t cr0 = s_croot[lane], cr1 = s_croot[live1 ? ci1 : 0u];
+            Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}}, c1 = {{cv1.x, cv1.y, cv1.z, cv1.w}};
+            const uint32_t nm0 = count_empty(c0), nm1 = count_empty(c1);
+            const unsigned long long b0 = __ballot(nm0 != 0u), b1 = __ballot(live1 && nm1 != 0u);
+            const uint32_t j0 = draws + prefix_count(b0), j1 = draws + (uint32_t)__popcll(b0) + prefix_count(b1);
+            draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+            spawn(c0, rng_draw(k0, k1, gid, j0));                                // :155 (a no-op on a full board)
+            spawn(c1, rng_draw(k0, k1, gid, j1));
+            const uint32_t pm0 = cr0 >> 8, pm1 = cr1 >> 8;
+            const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u), cm1 = pm1 + (has_code(c1, pm1 + 1u) ? 1u : 0u);
+            const uint32_t key0 = (eval_fast_u32_known(c0, nm0 - (nm0 ? 1u : 0u), cm0) << 9) + (511u - lane);
+            const uint32_t e1 = (eval_fast_u32_known(c1, nm1 - (nm1 ? 1u : 0u), cm1) << 9) + (511u - ci1);
+            const uint32_t key1 = live1 ? e1 : 0u;
+            s_cboard[lane] = make_uint4(c0.w[0], c0.w[1], c0.w[2], c0.w[3]);
+            s_croot[lane] = (cr0 & 0xffu) | (cm0 << 8);
+            if (live1) {
+                s_cboard[ci1] = make_uint4(c1.w[0], c1.w[1], c1.w[2], c1.w[3]);
+                s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
+            }
+            const uint32_t pick = 511u - (top64_desc(key0, key1, true) & 511u);
+            nb = width;                                                          // more than 64 children, width <= 32
+            __syncthreads();
+            if ((int)lane < nb) {
+                s_board[lane] = s_cboard[pick];
+                s_root[lane] = s_croot[pick];
+            }
+            __syncthreads();
+            continue;
+        }
+#endif
         const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u) && !(count_rank && fast);
         Board child[PASSES];
         double score[PASSES];
@@ -366,10 +418,10 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 const unsigned long long bc = __ballot(live && n_moved != 0u);
                 const uint32_t j = draws + prefix_count(bc);
                 draws += (uint32_t)__popcll(bc);
-#ifdef G2048_BEAM_SPAWN_SELECT
-                spawn(c, rng_draw(k0, k1, gid, j));                              // :118 / :155; a no-op on a full board
+#ifdef G2048_BEAM_SPAWN_PREFIX      // A/B (round 3: 2.7 % slower at 4096 games although it is 50 issue cycles cheaper per pass)
+                spawn_prefix(c, rng_draw(k0, k1, gid, j));
 #else
-                spawn_prefix(c, rng_draw(k0, k1, gid, j));                       // :118 / :155; a no-op on a full board
+                spawn(c, rng_draw(k0, k1, gid, j));                              // :118 / :155; a no-op on a full board
 #endif
                 // :122 / :158-161. What the evaluators need is already known: the empty count (one fewer after a spawn)
                 // and the max code -- a move raises the parent's max by at most one, exactly when some cell now holds
