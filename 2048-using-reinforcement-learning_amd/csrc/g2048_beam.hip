@@ -29,6 +29,8 @@ __device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // ---------------------------------------------------------------- ranking by sorting network
 // The fast levels rank unique 32-bit keys (score * 512 + 511 - generation index). All-pairs counting costs ~1.5 VALU
 // instructions per (key, lane) pair -- 190 to 240 per level at width 20 and two fifths of a decision's time. A bitonic
@@ -71,10 +73,10 @@ __device__ __forceinline__ uint32_t dpp_of(uint32_t v) { return (uint32_t)__buil
         "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                         \
         : "=&v"(out) : "v"(src), "s"(~keep_max) : "vcc")
 
-template <int K, int J>
-__device__ __forceinline__ uint32_t cx_step(uint32_t key)
+template <uint64_t KEEP_MAX, int J>
+__device__ __forceinline__ uint32_t cx_step_m(uint32_t key)
 {
-    constexpr uint64_t keep_max = cx_mask(K, J);
+    constexpr uint64_t keep_max = KEEP_MAX;
 #ifndef G2048_BEAM_CX_SUBCO          // default: v_max_dpp + v_min_dpp + v_cndmask (A/B switch: the two-instruction form below)
     {
         uint32_t hi, lo;
@@ -113,6 +115,9 @@ __device__ __forceinline__ uint32_t cx_step(uint32_t key)
 }
 #undef G2048_CX_DPP
 
+template <int K, int J>
+__device__ __forceinline__ uint32_t cx_step(uint32_t key) { return cx_step_m<cx_mask(K, J), J>(key); }
+
 // stages k = 2 .. KMAX of the 64-lane descending network: KMAX = 64 sorts the wavefront's keys, descending by lane; KMAX = 16
 // leaves every 16-lane row sorted, rows 0 and 2 descending, rows 1 and 3 ASCENDING
 template <int KMAX>
@@ -150,6 +155,26 @@ __device__ __forceinline__ uint32_t top64_desc(uint32_t a, uint32_t b, bool with
     if (!with_b) return a;
     b = sort_stages<16>(b);                                       // row 3 ascending
     return merge64_desc(pick_by_mask(a, b, 0xffff000000000000ull));
+}
+
+// The 32 largest of up to 128 keys held in two registers (a lane's two children in the lane-resident search below),
+// descending in lanes 0..31. The first ten stages sort all four 32-lane quarter sets at once -- a: lower half descending,
+// upper half ascending (the standard k <= 32 stages); b: the same stages with every direction inverted --, so max(a, b)
+// holds, in each half, the 32 largest of that half's two quarter sets as a bitonic sequence; five merge steps sort the halves
+// (lower descending, upper ascending), six more sort the whole. 26 step latencies, the two registers' steps independent of
+// each other (round 2's 64 + 16 arrangement: 37 steps in one dependent chain).
+__device__ __forceinline__ uint32_t top32_of_pair(uint32_t a, uint32_t b)
+{
+#define G2048_STEP2(K, J) a = cx_step_m<cx_mask(K, J), J>(a); b = cx_step_m<~cx_mask(K, J), J>(b);
+    G2048_STEP2(2, 1)
+    G2048_STEP2(4, 2) G2048_STEP2(4, 1)
+    G2048_STEP2(8, 4) G2048_STEP2(8, 2) G2048_STEP2(8, 1)
+    G2048_STEP2(16, 8) G2048_STEP2(16, 4) G2048_STEP2(16, 2) G2048_STEP2(16, 1)
+    G2048_STEP2(32, 16) G2048_STEP2(32, 8) G2048_STEP2(32, 4) G2048_STEP2(32, 2) G2048_STEP2(32, 1)
+#undef G2048_STEP2
+    uint32_t t = max(a, b);
+    t = cx_step<32, 16>(t); t = cx_step<32, 8>(t); t = cx_step<32, 4>(t); t = cx_step<32, 2>(t); t = cx_step<32, 1>(t);
+    return merge64_desc(t);
 }
 
 // The same network on 64-bit keys (hi, lo) for the levels whose scores are f64 (1..3): the partner's two words come through
@@ -220,6 +245,11 @@ __device__ __forceinline__ Key64 top64_desc64(Key64 a, Key64 b, bool with_b)
 
 __global__ __launch_bounds__(64) void sort_selftest_kernel(uint32_t *keys, const uint32_t *extra, int with_extra, int wide)
 {
+    if (wide == 2) {                             // pair mode: 64 + 64 keys, the 32 largest descending in lanes 0..31
+        const uint32_t a = keys[blockIdx.x * 64 + threadIdx.x], b = extra[blockIdx.x * 64 + threadIdx.x];
+        keys[blockIdx.x * 64 + threadIdx.x] = top32_of_pair(a, b);
+        return;
+    }
     if (wide) {                                  // 64-bit keys: (lo, hi) word pairs
         const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
         const Key64 a = {keys[2 * i + 1], keys[2 * i]};
@@ -252,6 +282,156 @@ struct BeamShared {
 
 struct Decision { uint32_t action; float prob; uint32_t expanded; };
 
+// ---------------------------------------------------------------- lane-resident search (round 3; beams up to 32 wide)
+// With four wavefronts per SIMD (4096 concurrent games) a search is bound by the latency of ITS OWN dependent instruction
+// chain, not by instruction issue: one wavefront alone runs at 35 % of a SIMD's issue rate, two at 55 %, four at 76 %
+// (profiles/r03_beam_latency.txt). This formulation is built for that chain:
+//   * lane = axis * 32 + p owns parent p's two children of one axis (lower half: LEFT / RIGHT, upper half: UP / DOWN) from the
+//     move to the key -- move, validity, spawn, score run as two independent instruction streams per lane, and nothing is
+//     compacted through LDS in between (round 2: children to LDS in generation order, barrier, read back 64 per pass);
+//   * generation order (parent rank, action) -- the reference's RNG consumption order and the tie order of its stable sort --
+//     comes from four half-wave ballots; a child's draw is its generation index minus the "changed but full" children before it
+//     (only the reference's rot180-DOWN quirk produces those);
+//   * the fast levels rank by top32_of_pair: four quarter sets sorted at once, 26 step latencies instead of 37;
+//   * the spawned children go to LDS at their generation index, the sorted keys ARE the next beam: the low nine bits of the
+//     key in lane r name the LDS slot of the rank-r child, lane 32 + r takes it through v_permlane32_swap, and the next level
+//     reads its parent from there -- no beam array, no barrier: one LDS read per level sits on the dependent chain (round 2:
+//     four round trips and three barriers);
+//   * levels 1..3 (f64 scores of _evaluate_state) rank by counting over the scores in LDS and hand the slots over through a
+//     small rank -> slot table.
+// LDS ordering needs no barrier: one wavefront's LDS operations execute in order, and every level reads its parents (one
+// instruction, all lanes) before it writes its children.
+template <int PASSES>
+__device__ __forceinline__ Decision beam_decide_lanes(BeamShared<PASSES> &sh, const Board &root, int mask_in, int width, int depth,
+                                                      uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1, uint64_t gid,
+                                                      bool fixed_down)
+{
+    uint4 *const s_child = sh.cboard;                  // spawned children of the current level, by generation index (<= 4 * 32)
+    uint32_t *const s_info = sh.croot;                 //   root action | max code << 8
+    double *const s_score = sh.score;                  // f64 levels: scores by generation index
+    uint32_t *const s_order = sh.root;                 // f64 levels: rank -> generation index
+    const uint32_t lane = threadIdx.x, p = lane & 31u;
+    const bool upper = lane >= 32u;                     // vertical axis: fwd = UP (1), rev = DOWN (3); lower: LEFT (0), RIGHT (2)
+    const uint32_t u = upper ? 1u : 0u;
+
+    const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);   // :82-93
+    const uint32_t nvalid = popc(mask);
+    if (nvalid <= 1u) return Decision{nvalid ? (uint32_t)__builtin_ctz(mask) : 0u, nvalid ? 1.0f : 0.5f, 0u};
+    const uint32_t root_max = max_code(root);                                                             // :96-106
+    const uint32_t phase = phase_of(root_max, early_thr, mid_thr);
+    const uint32_t root_empty = count_empty(root);
+    int actual_depth;
+    if (root_empty <= 4u) actual_depth = min(depth + 5, 25);
+    else if (root_empty >= 10u) actual_depth = min(depth - 5, 10);
+    else actual_depth = depth;
+
+    AxisSel asel = axis_sel(upper, fixed_down);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(asel.in[k]), "+v"(asel.fwd[k]), "+v"(asel.rev[k]));   // loop-invariant registers
+
+    int nb = 0;                      // beam size
+    uint32_t q = 0u;                 // LDS slot of this lane's parent (p < nb)
+    uint32_t best = 0u;              // LDS slot of the rank-0 child of the last ranked level (wave-uniform)
+    uint32_t draws = 0u, expanded = 0u;
+    for (int level = 0; level == 0 || level < actual_depth; ++level) {
+        const bool fast = level == 0 || level > 3;                               // :122, :139
+        const int n_parents = level == 0 ? 1 : nb;
+        const bool on = (int)p < n_parents;
+        Board P = root;
+        uint32_t ra_f = u | (root_max << 8), ra_r = (2u + u) | (root_max << 8);
+        bool en_f = on, en_r = on;
+        if (level == 0) {
+            en_f = on && ((mask >> u) & 1u);
+            en_r = on && ((mask >> (2u + u)) & 1u);
+        } else {
+            const uint4 pv = s_child[on ? q : 0u];
+            P = Board{{pv.x, pv.y, pv.z, pv.w}};
+            ra_f = ra_r = s_info[on ? q : 0u];
+        }
+        Board cf, cr;
+        move_axis_sel(P, asel, cf, cr);                                          // :115 / :152 (DOWN = rot180(true DOWN))
+        const bool vf = en_f && !same(cf, P), vr = en_r && !same(cr, P);
+        const uint32_t ef = count_empty(cf), er = count_empty(cr);
+        const unsigned long long bf = __ballot(vf), br = __ballot(vr);
+        // a child with an empty cell consumes the next draw, in generation order (:262-269); only the quirk's DOWN can be a
+        // "changed" board without one
+        const unsigned long long bx = __ballot(vr && er == 0u);
+        const uint32_t bf_lo = (uint32_t)bf, bf_hi = (uint32_t)(bf >> 32), br_lo = (uint32_t)br, br_hi = (uint32_t)(br >> 32);
+        const uint32_t total_valid = (uint32_t)__popcll(bf) + (uint32_t)__popcll(br);
+        if (total_valid == 0u) {
+            if (level == 0) {                                                   // :126-128 random valid action, prob 0.5
+                uint32_t idx = ((rng_draw(k0, k1, gid, draws) >> 16) * nvalid) >> 16;
+                uint32_t m = mask;
+                while (idx--) m &= m - 1u;
+                return Decision{(uint32_t)__builtin_ctz(m), 0.5f, 0u};
+            }
+            break;                                                              // :170-171 keep the previous beam
+        }
+        // valid children of the parents before p: bit p of the four half-ballots, counted below p (mbcnt_lo serves the lower
+        // lanes and returns the full count for the upper ones, mbcnt_hi serves the upper lanes: start those at -total)
+        uint32_t before = upper ? 0u - total_valid : 0u;
+        before = __builtin_amdgcn_mbcnt_lo(bf_lo, __builtin_amdgcn_mbcnt_lo(bf_hi, before));
+        before = __builtin_amdgcn_mbcnt_lo(br_lo, __builtin_amdgcn_mbcnt_lo(br_hi, before));
+        uint32_t before_hi = __builtin_amdgcn_mbcnt_hi(bf_lo, __builtin_amdgcn_mbcnt_hi(bf_hi, 0u));
+        before_hi = __builtin_amdgcn_mbcnt_hi(br_lo, __builtin_amdgcn_mbcnt_hi(br_hi, before_hi));
+        before += before_hi;
+        // the other axis of the same parent sits 32 lanes away; order inside a parent: LEFT UP RIGHT DOWN
+        const uint32_t mine = (vf ? 1u : 0u) | (vr ? 2u : 0u);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        const uint32_t other = upper ? sw[0] : sw[1];                             // [0] = {lower, lower}, [1] = {upper, upper}
+        const uint32_t g_f = before + (other & u);                                // UP comes after LEFT
+        const uint32_t g_r = before + (mine & 1u) + (other & 1u) + ((other >> 1) & u);   // RIGHT after LEFT UP; DOWN after all three
+        uint32_t xb = 0u;
+        if (bx) {                                                                // (rare) DOWNs without a draw among the parents before p
+            const uint32_t x = (uint32_t)(bx >> 32);
+            xb = upper ? __builtin_amdgcn_mbcnt_hi(x, 0u) : __builtin_amdgcn_mbcnt_lo(x, 0u);
+        }
+        spawn(cf, rng_draw(k0, k1, gid, draws + g_f - xb));                      // :118 / :155; a no-op on a full board
+        spawn(cr, rng_draw(k0, k1, gid, draws + g_r - xb));
+        draws += total_valid - (uint32_t)__popcll(bx);
+        expanded += total_valid;
+        // :122 / :158-161 with what is already known: the empty count (one fewer after a spawn) and the max code -- a move
+        // raises the parent's max by at most one, exactly when some cell now holds parent max + 1
+        const uint32_t pmax = ra_f >> 8;
+        const uint32_t cmf = pmax + (has_code(cf, pmax + 1u) ? 1u : 0u), cmr = pmax + (has_code(cr, pmax + 1u) ? 1u : 0u);
+        const uint32_t nf = ef - (ef ? 1u : 0u), nr = er - (er ? 1u : 0u);
+        if (vf) { s_child[g_f] = make_uint4(cf.w[0], cf.w[1], cf.w[2], cf.w[3]); s_info[g_f] = (ra_f & 0xffu) | (cmf << 8); }
+        if (vr) { s_child[g_r] = make_uint4(cr.w[0], cr.w[1], cr.w[2], cr.w[3]); s_info[g_r] = (ra_r & 0xffu) | (cmr << 8); }
+        nb = (int)min(total_valid, (uint32_t)width);                             // :132 / :175
+        if (fast) {
+            // unique keys score * 512 + (511 - generation index): their descending order is the stable order of :131 / :174
+            const uint32_t kf = vf ? (eval_fast_u32_known(cf, nf, cmf) << 9) + (511u - g_f) : 0u;
+            const uint32_t kr = vr ? (eval_fast_u32_known(cr, nr, cmr) << 9) + (511u - g_r) : 0u;
+            const uint32_t slot = 511u - (top32_of_pair(kf, kr) & 511u);         // lane r < nb: slot of the rank-r child
+            const auto sq = __builtin_amdgcn_permlane32_swap(slot, slot, false, false);
+            q = sq[0];                                                           // {lower, lower}: lane 32 + r takes lane r's
+            best = uniform(slot);
+        } else {
+            const double sf = eval_full_known(cf, phase, nf, cmf), sr = eval_full_known(cr, phase, nr, cmr);
+            if (vf) s_score[g_f] = sf;
+            if (vr) s_score[g_r] = sr;
+            if (lane == 0u) s_score[total_valid] = -INFINITY;                    // the pair read below may look one slot past the end
+            __syncthreads();
+            uint32_t rank_f = 0u, rank_r = 0u;                                   // stable descending rank (:131, :174)
+            for (uint32_t j = 0; j < total_valid; j += 2) {
+                const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
+                rank_f += (sj.x > sf || (sj.x == sf && j < g_f)) ? 1u : 0u;
+                rank_f += (sj.y > sf || (sj.y == sf && j + 1 < g_f)) ? 1u : 0u;
+                rank_r += (sj.x > sr || (sj.x == sr && j < g_r)) ? 1u : 0u;
+                rank_r += (sj.y > sr || (sj.y == sr && j + 1 < g_r)) ? 1u : 0u;
+            }
+            if (vf && rank_f < (uint32_t)width) s_order[rank_f] = g_f;
+            if (vr && rank_r < (uint32_t)width) s_order[rank_r] = g_r;
+            __syncthreads();
+            q = s_order[(int)p < nb ? p : 0u];
+            best = uniform(q);                                                   // lane 0 holds rank 0's slot
+        }
+    }
+    const Decision d = {s_info[best] & 0xffu, 1.0f, expanded};                   // :178-181
+    __syncthreads();                                                            // read before the caller reuses the LDS
+    return d;
+}
+
 // BeamSearchAgent.get_action for the game this wavefront owns. mask_in < 0: no caller mask. Every lane returns the same
 // Decision. Must be called by all 64 lanes (it contains workgroup barriers).
 //   stage A: lane 2p + axis makes BOTH moves of one axis of parent p (g2048_board.h move_axis), 32 parents per round; the
@@ -282,6 +462,13 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     const uint32_t lane = threadIdx.x;
     const bool fixed_down = (flags & 1u) != 0u;          // G2048_BEAM_FIXED_DOWN
     const bool count_rank = (flags & 2u) != 0u;          // G2048_BEAM_RANK_BY_COUNTING
+#ifdef G2048_BEAM_LANES
+    // A/B only: the lane-resident formulation above for beams up to 32 wide. Bit-exact (the whole GPU suite passes on it), but
+    // 11.6 % more vector instructions per decision and only 2 % less latency for a lone wavefront: 5.6 % slower at 4096 games,
+    // 7.6 % at 8192 (profiles/r03_beam_latency.txt)
+    if (PASSES <= 2 && !count_rank)
+        return beam_decide_lanes<PASSES>(sh, root, mask_in, width, depth, early_thr, mid_thr, k0, k1, gid, fixed_down);
+#endif
 
     // :82-93 -- caller mask or the agent's own validity; 0 or 1 valid move short-circuit
     const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);
@@ -298,6 +485,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
 
     int nb = 0;                    // current beam size
     uint32_t draws = 0, expanded = 0;
+    // After a level ranked by the sorting network the beam is not copied out: lane r keeps `pick`, the children-array slot of
+    // the rank-r child, and the next level's lanes fetch their parents from there (from_pick, wave-uniform) -- one LDS
+    // round trip and two barriers fewer per level. A wavefront's LDS operations execute in order, and a level reads all its
+    // parents (one instruction) before it writes any child.
+    bool from_pick = false;
+    uint32_t pick = 0u;
     // stage A's lane 2p + axis keeps its axis for the whole search: the direction network's selector words (rows -> lines,
     // forward lines -> rows, reversed lines -> rows with the agent's DOWN quirk folded in) are loop-invariant registers
     AxisSel asel = axis_sel((lane & 1u) != 0u, fixed_down);
@@ -319,6 +512,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             if (level == 0) {
                 en_f = on && ((mask >> (vertical ? 1 : 0)) & 1u);
                 en_r = on && ((mask >> (vertical ? 3 : 2)) & 1u);
+            } else if (from_pick) {                                              // (beams up to 32 wide: one round)
+                const uint32_t qs = (uint32_t)__shfl((int)pick, (int)(lane >> 1), 64);
+                const uint4 pv = s_cboard[on ? qs : 0u];
+                P = Board{{pv.x, pv.y, pv.z, pv.w}};
+                ra_f = ra_r = s_croot[on ? qs : 0u];
             } else if (on) {
                 const uint4 pv = s_board[par];
                 P = Board{{pv.x, pv.y, pv.z, pv.w}};
@@ -382,17 +580,22 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 s_cboard[ci1] = make_uint4(c1.w[0], c1.w[1], c1.w[2], c1.w[3]);
                 s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
             }
-            const uint32_t pick = 511u - (top64_desc(key0, key1, true) & 511u);
+            pick = 511u - (top64_desc(key0, key1, true) & 511u);
             nb = width;                                                          // more than 64 children, width <= 32
+#ifdef G2048_BEAM_COPY_BEAM             // A/B: round 2's hand-over through the beam array
             __syncthreads();
             if ((int)lane < nb) {
                 s_board[lane] = s_cboard[pick];
                 s_root[lane] = s_croot[pick];
             }
             __syncthreads();
+#else
+            from_pick = true;
+#endif
             continue;
         }
 #endif
+        from_pick = false;
         const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u) && !(count_rank && fast);
         Board child[PASSES];
         double score[PASSES];
@@ -450,7 +653,6 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 }
             const bool with_tail = PASSES == 2 && total_valid > 64u;
             nb = (int)min(total_valid, (uint32_t)width);
-            uint32_t pick;
             bool exact = !count_rank;                  // (the test switch: laid out for the network, ranked by counting)
             if (fast) {
                 // the keys are unique, so their descending order is the stable order of :131 / :174
@@ -484,12 +686,16 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 }
             }
             if (exact) {
+#ifdef G2048_BEAM_COPY_BEAM
                 __syncthreads();
                 if ((int)lane < nb) {
                     s_board[lane] = s_cboard[pick];
                     s_root[lane] = s_croot[pick];
                 }
                 __syncthreads();
+#else
+                from_pick = true;
+#endif
                 continue;
             }
         }
@@ -537,8 +743,8 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         nb = (int)min(total_valid, (uint32_t)width);
         __syncthreads();
     }
-    const Decision d = {s_root[0] & 0xffu, 1.0f, expanded};                     // :178-181
-    __syncthreads();                                                            // s_root[0] read before any reuse of the LDS
+    const Decision d = {(from_pick ? s_croot[uniform(pick)] : s_root[0]) & 0xffu, 1.0f, expanded};      // :178-181
+    __syncthreads();                                                            // read before any reuse of the LDS
     return d;
 }
 
@@ -731,7 +937,6 @@ __device__ __forceinline__ uint32_t ld_acquire(const uint32_t *p) { return __hip
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_release(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int PASSES>
 __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t *reg_list, SpecSlot *slots, uint32_t n_games,
@@ -1042,11 +1247,12 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
 int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream)
 {
     if (n_waves == 0) return G2048_OK;
-    if (!keys_inout || n_waves > 0x7fffffffu || (key_bits != 32 && key_bits != 64)) {
+    if (!keys_inout || n_waves > 0x7fffffffu || (key_bits != 32 && key_bits != 64 && key_bits != -32) ||
+        (key_bits == -32 && !extra_or_null)) {
         g2048_set_last_error_("g2048_sort_selftest: bad arguments"); return G2048_ERR_ARG;
     }
     hipLaunchKernelGGL(sort_selftest_kernel, dim3((unsigned)n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), keys_inout,
-                       extra_or_null, extra_or_null ? 1 : 0, key_bits == 64 ? 1 : 0);
+                       extra_or_null, extra_or_null ? 1 : 0, key_bits == 64 ? 1 : key_bits == -32 ? 2 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;

@@ -317,7 +317,9 @@ int g2048_shaping_apply(const void *next_boards, const uint8_t *state_maxcode, c
 int g2048_selftest(uint32_t *result_out, void *stream);
 /* the beam kernel's ranking network on its own (tests): every 64 keys of keys_inout become the 64 largest, descending, of
  * those 64 and -- if extra_or_null is given -- 16 more per block (0 = no key; all other keys distinct and > 0).
- * key_bits = 32: uint32 keys; 64: uint64 keys stored as (low word, high word), the network of the f64-score levels. */
+ * key_bits = 32: uint32 keys; 64: uint64 keys stored as (low word, high word), the network of the f64-score levels;
+ * -32: the pair network of the lane-resident search -- extra holds 64 more uint32 keys per block, and lanes 0..31 of every
+ * block receive the 32 largest of its 128 keys, descending (lanes 32..63: unspecified; 0 = no key, the others distinct). */
 int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream);
 
 #ifdef __cplusplus

@@ -197,6 +197,30 @@ def test_ranking_network_sorts(ops):
     assert torch.equal(dk.cpu().to(torch.int64)[:, :48], want)
 
 
+def test_ranking_network_pair_top32(ops):
+    """The lane-resident search's network (top32_of_pair): 64 + 64 keys in two registers, the 32 largest of the 128 come out
+    descending in lanes 0..31 -- full registers, sparse ones (keys only in lanes p < 20 of both halves, as a width-20 level has
+    them), one register empty, pre-sorted inputs."""
+    from g2048 import _lib as L
+    g = torch.Generator().manual_seed(11)
+    n_waves = 512
+    vals = (torch.randperm(1 << 24, generator=g)[: n_waves * 128] + 1).to(torch.int64).reshape(n_waves, 2, 64)
+    a, b = vals[:, 0].clone(), vals[:, 1].clone()
+    sparse = torch.zeros(64, dtype=torch.bool)
+    sparse[:20] = True; sparse[32:52] = True
+    a[10:200] *= sparse; b[10:200] *= sparse             # a width-20 level: lanes p < 20 of both halves
+    a[3] = 0                                            # one register without keys
+    b[4] = 0
+    a[5] = 0; b[5] = 0                                  # no keys at all
+    a[6] = torch.arange(128, 64, -1); b[6] = torch.arange(64, 0, -1)
+    a[7] = torch.arange(1, 65); b[7] = torch.arange(65, 129)
+    a[8, 1:] = 0; b[8] = 0                              # a single key
+    da, db = a.to(torch.int32).to(DEV).contiguous(), b.to(torch.int32).to(DEV).contiguous()
+    L.call(da.device, L.lib().g2048_sort_selftest, da.data_ptr(), db.data_ptr(), n_waves, -32, L.stream_ptr(da.device))
+    want = torch.sort(torch.cat([a, b], dim=1), dim=1, descending=True).values[:, :32]
+    assert torch.equal(da.cpu().to(torch.int64)[:, :32], want)
+
+
 def test_ranking_network_sorts_64_bit_keys(ops):
     """The 64-bit variant (levels whose scores are f64): keys differing only in the high word, only in the low word, above
     2^63 and below 2^31."""
