@@ -491,6 +491,16 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     // parents (one instruction) before it writes any child.
     bool from_pick = false;
     uint32_t pick = 0u;
+    // lane constants of the row-per-lane tail stream (row r = lane & 3 of a quad's child): masks for "odd row", "rows 2..3",
+    // "row 0 or 3", "not row 3", the flag "row 3", and the lane a tail key is fetched from (lane 48 + k <- quad k)
+    struct { uint32_t odd, low2, edge, notlast, fetch; bool last; } tq;
+    {
+        const uint32_t r = lane & 3u;
+        tq.odd = (r & 1u) ? ~0u : 0u; tq.low2 = r >= 2u ? ~0u : 0u; tq.edge = (r == 0u || r == 3u) ? ~0u : 0u;
+        tq.notlast = r != 3u ? ~0u : 0u; tq.last = r == 3u;
+        tq.fetch = lane >= 48u ? (lane - 48u) * 16u : lane * 4u;
+        asm volatile("" : "+v"(tq.odd), "+v"(tq.low2), "+v"(tq.edge), "+v"(tq.notlast), "+v"(tq.fetch));
+    }
     // stage A's lane 2p + axis keeps its axis for the whole search: the direction network's selector words (rows -> lines,
     // forward lines -> rows, reversed lines -> rows with the agent's DOWN quirk folded in) are loop-invariant registers
     AxisSel asel = axis_sel((lane & 1u) != 0u, fixed_down);
@@ -558,28 +568,79 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         // serial compare-exchange steps leave open: with four wavefronts per SIMD (4096 games) the search is bound by each
         // wavefront's own latency, not by instruction issue (profiles/r03_beam_latency.txt).
         if (PASSES == 2 && fast && !count_rank && total_valid > 64u && total_valid <= 80u) {
+            // first stream: children 0..63, one per lane
+            const uint4 cv0 = s_cboard[lane];
+            const uint32_t cr0 = s_croot[lane];
+            Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}};
+            const uint32_t nm0 = count_empty(c0);
+            const unsigned long long b0 = __ballot(nm0 != 0u);
+            const uint32_t j0 = draws + prefix_count(b0);
+#ifdef G2048_BEAM_TAIL_BOARDS       // A/B: round 2's second pass -- a whole board per lane in lanes 48..63 (147 instructions for <= 16 children)
             const uint32_t ci1 = lane + 16u;
             const bool live1 = lane >= 48u && ci1 < total_valid;
-            const uint4 cv0 = s_cboard[lane], cv1 = s_cboard[live1 ? ci1 : 0u];
-            const uint32_t cr0 = s_croot[lane], cr1 = s_croot[live1 ? ci1 : 0u];
-            Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}}, c1 = {{cv1.x, cv1.y, cv1.z, cv1.w}};
-            const uint32_t nm0 = count_empty(c0), nm1 = count_empty(c1);
-            const unsigned long long b0 = __ballot(nm0 != 0u), b1 = __ballot(live1 && nm1 != 0u);
-            const uint32_t j0 = draws + prefix_count(b0), j1 = draws + (uint32_t)__popcll(b0) + prefix_count(b1);
-            draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-            spawn(c0, rng_draw(k0, k1, gid, j0));                                // :155 (a no-op on a full board)
+            const uint4 cv1 = s_cboard[live1 ? ci1 : 0u];
+            const uint32_t cr1 = s_croot[live1 ? ci1 : 0u];
+            Board c1 = {{cv1.x, cv1.y, cv1.z, cv1.w}};
+            const uint32_t nm1 = count_empty(c1);
+            const unsigned long long b1 = __ballot(live1 && nm1 != 0u);
+            const uint32_t j1 = draws + (uint32_t)__popcll(b0) + prefix_count(b1);
             spawn(c1, rng_draw(k0, k1, gid, j1));
-            const uint32_t pm0 = cr0 >> 8, pm1 = cr1 >> 8;
-            const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u), cm1 = pm1 + (has_code(c1, pm1 + 1u) ? 1u : 0u);
-            const uint32_t key0 = (eval_fast_u32_known(c0, nm0 - (nm0 ? 1u : 0u), cm0) << 9) + (511u - lane);
+            const uint32_t pm1 = cr1 >> 8;
+            const uint32_t cm1 = pm1 + (has_code(c1, pm1 + 1u) ? 1u : 0u);
             const uint32_t e1 = (eval_fast_u32_known(c1, nm1 - (nm1 ? 1u : 0u), cm1) << 9) + (511u - ci1);
             const uint32_t key1 = live1 ? e1 : 0u;
-            s_cboard[lane] = make_uint4(c0.w[0], c0.w[1], c0.w[2], c0.w[3]);
-            s_croot[lane] = (cr0 & 0xffu) | (cm0 << 8);
             if (live1) {
                 s_cboard[ci1] = make_uint4(c1.w[0], c1.w[1], c1.w[2], c1.w[3]);
                 s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
             }
+#else
+            // second stream: children 64..79, one ROW per lane -- lane 4k + r holds row r of child 64 + k, so the 16 children
+            // fill the wavefront instead of a quarter of it; what spans the board (empty count, rank of the spawn cell, max
+            // code, corners, vertical neighbours) moves between the four lanes of a quad through DPP quad permutes. 84 vector
+            // instructions instead of 147, and independent of the first stream until the network.
+            const uint32_t ci1 = 64u + (lane >> 2);
+            const bool live1 = ci1 < total_valid;
+            uint32_t w1 = reinterpret_cast<const uint32_t *>(s_cboard)[256u + lane];
+            const uint32_t cr1 = s_croot[ci1];                                   // (slots up to 127 exist; dead ones hold stale data)
+            const uint32_t z1 = zflag(w1), cnt1 = popc(z1);
+            const uint32_t pair1 = cnt1 + dpp_of<0xB1>(cnt1);                     // rows {0,1} / {2,3}
+            const uint32_t nm1 = pair1 + dpp_of<0x4E>(pair1);                     // empty cells of the child, in all four lanes
+            const uint32_t above1 = (dpp_of<0xA0>(cnt1) & tq.odd) + (dpp_of<0x00>(pair1) & tq.low2);      // empty cells in the rows above
+            const unsigned long long b1 = __ballot(live1 && nm1 != 0u && tq.last);
+            const uint32_t j1 = draws + (uint32_t)__popcll(b0) + prefix_count(b1);  // (lanes of a quad count the quads before theirs)
+            const uint32_t h1 = rng_draw(k0, k1, gid, j1);
+            const uint32_t k1_ = ((((h1 >> 16) * nm1) >> 16) - above1);           // rank of the spawn cell inside this row, if it is here
+            {
+                const uint32_t ones = 0x01010101u;
+                const uint32_t target = k1_ < cnt1 ? (k1_ + 1u) * ones : 0x7f7f7f7fu;
+                const uint32_t hit = zflag(((z1 >> 7) * ones) ^ target) & z1;
+                w1 |= hit >> (((h1 & 0xffffu) >= 58982u) ? 6u : 7u);
+            }
+            const uint32_t pm1 = cr1 >> 8;
+            uint32_t f1 = zflag(w1 ^ ((pm1 + 1u) * 0x01010101u));                 // some cell holds parent max + 1?
+            f1 |= dpp_of<0xB1>(f1); f1 |= dpp_of<0x4E>(f1);
+            const uint32_t cm1 = pm1 + (f1 ? 1u : 0u);
+            uint32_t cc1 = max(w1 & 0xffu, w1 >> 24) & tq.edge;                   // corners live in rows 0 and 3
+            cc1 = max(cc1, dpp_of<0xB1>(cc1)); cc1 = max(cc1, dpp_of<0x4E>(cc1));
+            const uint32_t n1 = w1 + B7F;
+            uint32_t pr1 = popc(n1 & ~((w1 ^ (w1 >> 8)) + B7F) & B80);           // equal non-zero neighbours in the row ...
+            pr1 += popc(n1 & ~((w1 ^ dpp_of<0xF9>(w1)) + B7F) & B80 & tq.notlast);  // ... and towards the row below
+            pr1 += dpp_of<0xB1>(pr1); pr1 += dpp_of<0x4E>(pr1);
+            const uint32_t sc1 = (nm1 - (nm1 ? 1u : 0u)) * 10u + cm1 * 2u + (cc1 ? (2u << cc1) : 0u) + pr1 * 2u;
+            const uint32_t e1 = live1 ? (sc1 << 9) + (511u - ci1) : 0u;
+            const uint32_t key1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)tq.fetch, (int)e1);   // lane 48 + k <- quad k
+            if (live1) {
+                reinterpret_cast<uint32_t *>(s_cboard)[256u + lane] = w1;
+                if (tq.last) s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
+            }
+#endif
+            spawn(c0, rng_draw(k0, k1, gid, j0));                                // :155 (a no-op on a full board)
+            draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+            const uint32_t pm0 = cr0 >> 8;
+            const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
+            const uint32_t key0 = (eval_fast_u32_known(c0, nm0 - (nm0 ? 1u : 0u), cm0) << 9) + (511u - lane);
+            s_cboard[lane] = make_uint4(c0.w[0], c0.w[1], c0.w[2], c0.w[3]);
+            s_croot[lane] = (cr0 & 0xffu) | (cm0 << 8);
             pick = 511u - (top64_desc(key0, key1, true) & 511u);
             nb = width;                                                          // more than 64 children, width <= 32
 #ifdef G2048_BEAM_COPY_BEAM             // A/B: round 2's hand-over through the beam array
