@@ -151,9 +151,18 @@ __device__ __forceinline__ uint32_t merge64_desc(uint32_t key)
 // union, which is all a beam of width <= 32 takes.
 __device__ __forceinline__ uint32_t top64_desc(uint32_t a, uint32_t b, bool with_b)
 {
-    a = sort_stages<64>(a);
-    if (!with_b) return a;
-    b = sort_stages<16>(b);                                       // row 3 ascending
+    if (!with_b) return sort_stages<64>(a);
+    // the two sorts are independent: their first ten steps are written alternately, so that one register's compare-exchange
+    // fills the wait states and the latency of the other's (a wavefront's own latency is what bounds a search at four
+    // wavefronts per SIMD)
+#define G2048_STEP_AB(K, J) a = cx_step<K, J>(a); b = cx_step<K, J>(b);
+    G2048_STEP_AB(2, 1)
+    G2048_STEP_AB(4, 2) G2048_STEP_AB(4, 1)
+    G2048_STEP_AB(8, 4) G2048_STEP_AB(8, 2) G2048_STEP_AB(8, 1)
+    G2048_STEP_AB(16, 8) G2048_STEP_AB(16, 4) G2048_STEP_AB(16, 2) G2048_STEP_AB(16, 1)         // b: row 3 ascending
+#undef G2048_STEP_AB
+    a = cx_step<32, 16>(a); a = cx_step<32, 8>(a); a = cx_step<32, 4>(a); a = cx_step<32, 2>(a); a = cx_step<32, 1>(a);
+    a = merge64_desc(a);
     return merge64_desc(pick_by_mask(a, b, 0xffff000000000000ull));
 }
 
