@@ -22,7 +22,43 @@ using namespace g2048;
 namespace {
 
 constexpr int kMaxWidth = G2048_BEAM_MAX_WIDTH;
-constexpr size_t kOrderMinGames = 4096, kOrderMaxGames = 1u << 20;      // batches that get the balanced block order (at 2048 it costs more than it gains)
+constexpr size_t kOrderMaxGames = 1u << 20;
+constexpr int kSimdsPerCu = 4, kFallbackCus = 256;     // CDNA: four SIMDs per compute unit; MI355X's CU count if the device cannot be asked
+
+// Launch arithmetic that depends on the chip's size, all of it from the compute-unit count of the device the call runs on
+// (hipDeviceGetAttribute, asked per call: a partitioned or CU-masked device simply reports fewer):
+//   order_row      blocks b, b + row, b + 2 row ... of a one-wavefront-per-block launch share a SIMD when row = the number of
+//                  SIMDs (measured on MI355X, tools/ubench/placement.hip): beam_order_kernel deals the games in rows of it;
+//   order_min      the balanced order pays from four searches per SIMD on (at two it costs more than it gains);
+//   helper_cap     helper wavefronts never take more than a quarter of the wavefronts the chip holds at once (resident blocks
+//                  per CU x CUs / 4), so that owners find room whatever the dispatch order.
+struct LaunchPlan { uint32_t order_row, order_min, helper_cap; };
+constexpr LaunchPlan launch_plan(int cus, int resident_blocks_per_cu)
+{
+    const uint32_t c = cus > 0 ? (uint32_t)cus : (uint32_t)kFallbackCus;
+    const uint32_t b = resident_blocks_per_cu > 0 ? (uint32_t)resident_blocks_per_cu : 32u;
+    return LaunchPlan{c * kSimdsPerCu, 4u * c * kSimdsPerCu, c * b / 4u > 0u ? c * b / 4u : 1u};
+}
+static_assert(launch_plan(256, 32).order_row == 1024 && launch_plan(256, 32).order_min == 4096 && launch_plan(256, 32).helper_cap == 2048,
+              "MI355X: the values rounds 1-2 had hard-coded");
+
+constexpr uint32_t kSpecSlotsPerGame = 8;       // = kSpec below
+constexpr uint32_t default_helpers(uint32_t n_games, uint32_t helper_cap)
+{
+    const uint32_t want = n_games / 4u > 1024u ? n_games / 4u : 1024u;
+    const uint32_t most = kSpecSlotsPerGame * n_games < want ? kSpecSlotsPerGame * n_games : want;
+    return most < helper_cap ? most : helper_cap;
+}
+
+int device_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return kFallbackCus;
+    }
+    return cus;
+}
 
 __device__ __forceinline__ uint32_t prefix_count(unsigned long long ballot)
 {
@@ -818,11 +854,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     return d;
 }
 
-// Blocks b, b + 1024, b + 2048, ... of a one-wavefront-per-block launch share a SIMD on MI355X (256 CUs x 4 SIMDs; measured,
-// tools/ubench/placement.hip), and a launch lasts as long as its most loaded SIMD: with the games in caller order the
+// Blocks b, b + row_len, b + 2 row_len, ... of a one-wavefront-per-block launch share a SIMD when row_len is the chip's SIMD
+// count (MI355X: 256 CUs x 4 = 1024; measured, tools/ubench/placement.hip; the caller passes launch_plan().order_row), and a launch lasts as long as its most loaded SIMD: with the games in caller order the
 // heaviest SIMD of the benchmark batch carries 17 % more children than the mean. A decision's cost is its depth, which
 // takes one of three values fixed by the root's empty cells (beam_decide :96-106); order[b] = the game block b searches:
-// the games sorted by that class, deepest first, dealt to the SIMDs in rows of 1024 that alternate direction, so that every
+// the games sorted by that class, deepest first, dealt to the SIMDs in rows of row_len that alternate direction, so that every
 // SIMD gets deep and shallow searches (launch 145 -> 128 us when the order is free, profiles/r02_beam_balance.txt).
 // Deepest-first is also the order that keeps the tail short when the batch is larger than the chip holds at once.
 // One block; a counting sort whose per-class counts are wave ballots (two LDS atomics per wavefront and class in all).
@@ -834,7 +870,7 @@ __device__ __forceinline__ uint32_t depth_class(const uint4 &rv)         // 0 de
 }
 
 __global__ __launch_bounds__(1024) void beam_order_kernel(const uint4 *__restrict__ roots, uint32_t *__restrict__ order, uint32_t n,
-                                                         int depth)
+                                                         int depth, uint32_t row_len)
 {
     __shared__ uint32_t s_count[3], s_cursor[3];
     constexpr int kHeld = 8;                                 // classes of the first 8192 games stay in registers
@@ -875,13 +911,13 @@ __global__ __launch_bounds__(1024) void beam_order_kernel(const uint4 *__restric
     if (lane < 3) base = atomicAdd(&s_cursor[lane], mine);
     uint32_t at0 = start0 + (uint32_t)__builtin_amdgcn_readlane((int)base, 0), at1 = start1 + (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
     uint32_t at2 = start2 + (uint32_t)__builtin_amdgcn_readlane((int)base, 2);
-    const uint32_t rows = (n + 1023u) >> 10;
+    const uint32_t rows = (n + row_len - 1u) / row_len;
     auto place = [&](uint32_t i, uint32_t cls) {
         const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
         const uint32_t r = cls == 0u ? at0 + prefix_count(m0) : cls == 1u ? at1 + prefix_count(m1) : at2 + prefix_count(m2);
         at0 += (uint32_t)__popcll(m0); at1 += (uint32_t)__popcll(m1); at2 += (uint32_t)__popcll(m2);
-        const uint32_t row = r >> 10, q = r & 1023u, len = row + 1u == rows ? n - (row << 10) : 1024u;
-        if (cls < 3u) order[(row << 10) + ((row & 1u) ? len - 1u - q : q)] = i;
+        const uint32_t row = r / row_len, q = r - row * row_len, len = row + 1u == rows ? n - row * row_len : row_len;
+        if (cls < 3u) order[row * row_len + ((row & 1u) ? len - 1u - q : q)] = i;
     };
 #pragma unroll
     for (int k = 0; k < kHeld; ++k) if ((uint32_t)k * 1024u < n) place((uint32_t)k * 1024u + threadIdx.x, held[k]);
@@ -989,7 +1025,7 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
 // would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
 // Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
-constexpr int kSpec = 8;
+constexpr int kSpec = (int)kSpecSlotsPerGame;
 constexpr size_t kSpecMaxGames = 1u << 16;           // beyond this the workspace is not worth it: one wavefront per game
 constexpr uint32_t kNone = 0xffffffffu;
 
@@ -1001,7 +1037,7 @@ struct SpecSlot {                 // 64 bytes per (game, slot), in the workspace
     uint32_t res_seq;             // stored last by the helper: the result answers request res_seq
     uint32_t pad[6];
 };
-struct SpecCtl { uint32_t resolved, registered, next_unit, pad; };
+struct SpecCtl { uint32_t resolved, registered, next_unit, started; };     // started: owner blocks that have begun
 
 __device__ __forceinline__ uint32_t ld_acquire(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1020,10 +1056,14 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
         const uint32_t ticket = u / kSpec, k = u % kSpec;
         if (ticket >= n_games) return;
         uint32_t g;
-        for (;;) {                                                   // until the ticket's game exists, or no game is left
+        // until the ticket's game exists, or no game is left. A helper only idles here while every owner block is on the chip:
+        // should the dispatcher have placed helpers while owners still wait for a slot (a partitioned or smaller device, an
+        // out-of-order dispatch), it gives its slot back after a bounded wait -- owners never depend on helpers.
+        for (uint32_t idle = 0;; ++idle) {
             g = uniform(ld_acquire(&reg_list[ticket]));
             if (g != kNone) break;
             if (uniform(ld_relaxed(&ctl->resolved)) >= n_games) return;
+            if (idle >= 64u && uniform(ld_relaxed(&ctl->started)) < n_games) return;       // ~64 x 3.4 us
             for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
         }
         SpecSlot *slot = slots + (size_t)g * kSpec + k;
@@ -1073,6 +1113,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
     const uint4 rv = boards[g];
     GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     SpecSlot *const my = slots + g * kSpec;
+    if (lane == 0) atomicAdd(&ctl->started, 1u);
     bool registered = false;
     uint32_t seq = 0u;
     int stuck = 0;                                                   // invalid moves minus valid ones, floored at 0
@@ -1178,9 +1219,10 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
     // with scratch for it, and a batch of at least four searches per SIMD, the blocks take the games in a depth-balanced order
     uint32_t *order = nullptr;
-    if (order_ws && n_games >= kOrderMinGames && n_games <= kOrderMaxGames) {
+    const LaunchPlan plan = launch_plan(order_ws ? device_cus() : 0, 0);
+    if (order_ws && n_games >= plan.order_min && n_games <= kOrderMaxGames) {
         order = order_ws;
-        hipLaunchKernelGGL(beam_order_kernel, dim3(1), dim3(1024), 0, s, roots, order, (uint32_t)n_games, depth);
+        hipLaunchKernelGGL(beam_order_kernel, dim3(1), dim3(1024), 0, s, roots, order, (uint32_t)n_games, depth, plan.order_row);
     }
     {
 #define G2048_LAUNCH_BEAM(P) hipLaunchKernelGGL(beam_kernel<P>, grid, dim3(64), 0, s, roots, valid_mask_or_null, action_out, prob_out, \
@@ -1207,7 +1249,8 @@ static size_t play_workspace_bytes(size_t n_games)
 static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
                      int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
                      int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
-                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, void *caller_ws)
+                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, void *caller_ws,
+                     const uint32_t *tuning = nullptr)
 {
     if (n_games == 0) return G2048_OK;
     if (!boards_inout || !score_inout || !moves_out || !valid_out || !invalid_out || !milestone_move_out || !alive_out) {
@@ -1235,23 +1278,31 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         else G2048_LAUNCH_PLAY(8);
 #undef G2048_LAUNCH_PLAY
     } else {
-        // Helpers: four per game for a small batch, a quarter of the games for a large one, never more than 2048 wavefronts
-        // (a quarter of the chip's wave slots, so owners always find room whatever the dispatch order). A game registers
-        // for them once it is stuck (16 more invalid than valid moves lately) or once an eighth of the games (at least 256)
-        // is left; an owner polls at most 60 us for a posted result. Measured flat around these values
-        // (profiles/r02_eval_helpers.txt); G2048_PLAY_TUNE = "helpers,games_left,stuck,wait_us" overrides them for
-        // measurements.
+        // Helpers: four per game for a small batch, a quarter of the games for a large one, never more than a quarter of the
+        // wavefronts the device holds at once (launch_plan: CUs x resident blocks per CU / 4 -- 2048 on a whole MI355X), so
+        // owners always find room whatever the dispatch order. A game registers for them once it is stuck (16 more invalid
+        // than valid moves lately) or once an eighth of the games (at least 256) is left; an owner polls at most 60 us for a
+        // posted result. Measured flat around these values (profiles/r02_eval_helpers.txt); g2048_play_games_tuned overrides
+        // them for measurements and tests (every field clamped).
         const uint32_t n = (uint32_t)n_games;
-        uint32_t helpers = std::min<uint32_t>(std::min<uint32_t>((uint32_t)kSpec * n, std::max<uint32_t>(n / 4u, 1024u)), 2048u);
+        int resident = 0;
+        {
+            hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, 0)
+                          : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, 0)
+                          : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, 0);
+            if (oe != hipSuccess) { (void)hipGetLastError(); resident = 0; }
+        }
+        const LaunchPlan plan = launch_plan(device_cus(), resident);
+        uint32_t helpers = default_helpers(n, plan.helper_cap);
         uint32_t games_left = std::max<uint32_t>(n / 8u, 256u);
         int stuck_thr = 16;
         uint32_t wait_us = 60;
-        if (const char *tune = getenv("G2048_PLAY_TUNE")) {
-            unsigned h = helpers, l = games_left, w = wait_us; int st = stuck_thr;
-            if (sscanf(tune, "%u,%u,%d,%u", &h, &l, &st, &w) >= 1) {
-                helpers = std::min<uint32_t>(std::min<uint32_t>(h, (uint32_t)kSpec * n), 2048u);
-                games_left = l; stuck_thr = st; wait_us = std::min<uint32_t>(w, 1000u);
-            }
+        if (tuning) {
+            helpers = std::min<uint32_t>(std::min<uint32_t>(tuning[0], (uint32_t)kSpec * n), plan.helper_cap);
+            games_left = tuning[1];
+            stuck_thr = (int)std::min<uint32_t>(std::max<uint32_t>(tuning[2], 1u), 1u << 20);
+            wait_us = std::min<uint32_t>(tuning[3], 1000u);
         }
         const uint32_t reg_resolved = games_left >= n ? 0u : n - games_left;
         const size_t list_bytes = (n_games * sizeof(uint32_t) + 63u) & ~(size_t)63u;
@@ -1264,8 +1315,12 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         SpecCtl *ctl = reinterpret_cast<SpecCtl *>(ws);
         uint32_t *reg_list = reinterpret_cast<uint32_t *>(ws + 64);
         SpecSlot *slots = reinterpret_cast<SpecSlot *>(ws + 64 + list_bytes);
-        (void)hipMemsetAsync(ws, 0, bytes, s);
-        (void)hipMemsetAsync(reg_list, 0xff, list_bytes, s);
+        hipError_t me = hipMemsetAsync(ws, 0, bytes, s);
+        if (me == hipSuccess) me = hipMemsetAsync(reg_list, 0xff, list_bytes, s);
+        if (me != hipSuccess) {
+            if (!caller_ws) (void)hipFreeAsync(ws, s);
+            g2048_set_last_error_(hipGetErrorString(me)); return G2048_ERR_HIP;
+        }
         const dim3 grid((unsigned)(n + helpers));
 #define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
                                                 stuck_thr, reg_resolved, wait_us * 100u)
@@ -1314,6 +1369,34 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
                      (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace);
 }
 
+int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
+                           int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                           int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
+                           uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace, size_t workspace_bytes,
+                           const uint32_t *tuning4, void *stream)
+{
+    if (!tuning4) { g2048_set_last_error_("g2048_play_games_tuned: null tuning"); return G2048_ERR_ARG; }
+    const size_t need = g2048_play_games_workspace(n_games);
+    if (!workspace || need == 0) opts |= G2048_PLAY_ONE_PHASE;
+    else if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 63u)) {
+        g2048_set_last_error_("g2048_play_games_tuned: workspace smaller than g2048_play_games_workspace(n_games) or not 64-byte aligned");
+        return G2048_ERR_ARG;
+    }
+    return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
+                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace, tuning4);
+}
+
+int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_games, uint32_t *out4)
+{
+    if (!out4 || compute_units < 0 || resident_blocks_per_cu < 0 || n_games > 0xffffffffu) {
+        g2048_set_last_error_("g2048_launch_plan: bad arguments"); return G2048_ERR_ARG;
+    }
+    const LaunchPlan p = launch_plan(compute_units ? compute_units : device_cus(), resident_blocks_per_cu);
+    out4[0] = p.order_row; out4[1] = p.order_min; out4[2] = p.helper_cap; out4[3] = default_helpers((uint32_t)n_games, p.helper_cap);
+    return G2048_OK;
+}
+
 int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream)
 {
     if (n_waves == 0) return G2048_OK;
@@ -1339,7 +1422,7 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
 
 size_t g2048_beam_workspace_bytes(size_t n_games)
 {
-    return (n_games >= kOrderMinGames && n_games <= kOrderMaxGames) ? n_games * sizeof(uint32_t) : 0;
+    return (n_games >= launch_plan(device_cus(), 0).order_min && n_games <= kOrderMaxGames) ? n_games * sizeof(uint32_t) : 0;
 }
 
 int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,

@@ -14,6 +14,7 @@ from . import _build
 _lib = None
 
 OK = 0
+ABI_VERSION = 2
 FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
 STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS, STEP_NOOP_ACTIONS = 0x01, 0x02, 0x04, 0x08
 VALID_ENV, VALID_AGENT = 0, 1
@@ -49,6 +50,9 @@ SIGNATURES = {
     "g2048_play_games_workspace": (_sz, [_sz]),
     "g2048_play_games_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp, _sz,
                                   _vp]),
+    "g2048_play_games_tuned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp,
+                                     _sz, _vp, _vp]),
+    "g2048_launch_plan": (_int, [_int, _int, _sz, _vp]),
     "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_unpack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_synth_boards": (_int, [_vp, _u64, _u64, _sz, _u32, _u32, _vp]),
@@ -82,12 +86,17 @@ def lib():
         if not os.path.exists(path):
             raise RuntimeError("g2048: %s is missing -- build it with `python __graft_entry__.py` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        if os.environ.get("G2048_LIB"):      # A/B builds (tools/build_ab.sh) are only ever loaded on request, and say so
+            import sys
+            print("g2048: loading the A/B build %s (G2048_LIB is set)" % path, file=sys.stderr)
+        elif os.path.basename(path) != "libg2048_hip.so":
+            raise RuntimeError("g2048: refusing to load %s: only csrc/libg2048_hip.so is the product library" % path)
         L = C.CDLL(path)        # torch is imported above, so libamdhip64 resolves to the runtime torch uses
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError here = ABI mismatch, deliberately loud
             fn.restype, fn.argtypes = res, args
-        if L.g2048_abi_version() != 1:
-            raise RuntimeError("g2048: ABI version mismatch")
+        if L.g2048_abi_version() != ABI_VERSION:
+            raise RuntimeError("g2048: ABI version mismatch (library %d, binding %d)" % (L.g2048_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -29,11 +29,13 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)      # evaluate_beam_se
 
 def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x2048, max_moves=5000,
                          device="cuda", game_id_base=0, check_every=64, early_game_threshold=512,
-                         mid_game_threshold=1024, fixed_down=False, use_graph=True, fused=True, one_phase=False, _table_only=False):
+                         mid_game_threshold=1024, fixed_down=False, use_graph=True, fused=True, one_phase=False, _table_only=False,
+                         tuning=None):
     """fused=True (default): every game is played start to finish by its own wavefront in one kernel launch
     (`g2048_play_games`; helper wavefronts of that launch pre-compute decisions for the last games, one_phase=True turns
     them off -- same games). fused=False: the step-by-step loop (one beam launch + one step launch + bookkeeping per move for
-    the whole batch; with use_graph=True a captured hipGraph of one move is replayed). All three produce identical games."""
+    the whole batch; with use_graph=True a captured hipGraph of one move is replayed). All three produce identical games.
+    tuning = (helpers, games_left, stuck, wait_us): explicit helper-wavefront parameters (ops.play_games; measurements, tests)."""
     dev = torch.device(device)
     n = int(num_games)
     t_start = time.perf_counter()
@@ -48,7 +50,7 @@ def evaluate_beam_search(num_games=4096, beam_width=20, search_depth=30, seed=0x
     graph = None
     if fused:
         res = ops.play_games(env.boards, env.scores, beam_width, search_depth, max_moves, early_game_threshold,
-                             mid_game_threshold, seed, game_id_base, fixed_down, one_phase)
+                             mid_game_threshold, seed, game_id_base, fixed_down, one_phase, tuning=tuning)
         alive, moves, valid_cnt, invalid_cnt = res["alive"], res["moves"], res["valid_moves"], res["invalid_moves"]
         ms_move, expanded_sum = res["milestone_move"], res["expanded"]
         t = max_moves

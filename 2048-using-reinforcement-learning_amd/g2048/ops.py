@@ -518,13 +518,14 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
 
 
 def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512, mid_threshold=1024, seed=0x2048,
-               game_id_base=0, fixed_down=False, one_phase=False, rank_by_counting=False):
+               game_id_base=0, fixed_down=False, one_phase=False, rank_by_counting=False, tuning=None):
     """Every game played to completion in ONE launch (beam get_action -> env step fused per game, reference
     run_evaluation.py:48-69): one wavefront owns a game; helper wavefronts of the same launch search the boards the next
     moves can start from ahead of time, for the games that are left when the chip empties (g2048_beam.hip;
     one_phase=True plays without them -- the games are identical). boards / scores are updated in place. Returns a dict
     of per-game tensors: moves, valid_moves, invalid_moves (int32), milestone_move (int32 (n,8), -1 = never), expanded
-    (int64), alive (uint8)."""
+    (int64), alive (uint8). tuning = (helpers, games_left, stuck, wait_us): the helper-wavefront parameters given explicitly
+    (g2048_play_games_tuned; measurements and tests -- the games are the same for every setting)."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     _require_scores(scores)
     n = boards.shape[0]
@@ -540,14 +541,29 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
     # the helpers' request slots: caller-owned scratch, like every other buffer of the interface
     ws_bytes = 0 if one_phase else int(L.lib().g2048_play_games_workspace(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-    L.call(dev, L.lib().g2048_play_games_ws, boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
-           out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
-           out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
-           int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
-           (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0) |
-           (L.BEAM_RANK_BY_COUNTING if rank_by_counting else 0),
-           ws.data_ptr() if ws is not None else None, ws_bytes, L.stream_ptr(dev))
+    args = (boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
+            out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
+            out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
+            int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
+            (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0) |
+            (L.BEAM_RANK_BY_COUNTING if rank_by_counting else 0),
+            ws.data_ptr() if ws is not None else None, ws_bytes)
+    if tuning is not None:
+        import ctypes
+        t4 = (ctypes.c_uint32 * 4)(*[min(max(int(x), 0), 0xFFFFFFFF) for x in tuning])
+        L.call(dev, L.lib().g2048_play_games_tuned, *args, ctypes.cast(t4, ctypes.c_void_p), L.stream_ptr(dev))
+    else:
+        L.call(dev, L.lib().g2048_play_games_ws, *args, L.stream_ptr(dev))
     return out
+
+
+def launch_plan(compute_units=0, resident_blocks_per_cu=0, n_games=0):
+    """The chip-size arithmetic of the library (g2048_launch_plan; a host function, usable without a GPU when compute_units
+    is given): dict(order_row, order_min_games, helper_cap, default_helpers)."""
+    import ctypes
+    out = (ctypes.c_uint32 * 4)()
+    L.check(L.lib().g2048_launch_plan(int(compute_units), int(resident_blocks_per_cu), int(n_games), ctypes.cast(out, ctypes.c_void_p)))
+    return dict(order_row=out[0], order_min_games=out[1], helper_cap=out[2], default_helpers=out[3])
 
 
 def selftest(device="cuda"):

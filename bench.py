@@ -14,9 +14,11 @@ and relays its exit code; the parent itself never touches the GPU (no torch impo
 
 Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs, max over ranks.
 The K launches are replayed from one hipGraph (launch-bound otherwise: a step is ~10-15 us of GPU time);
-pass --no-graph for eager launches. The roofline leg is the same K launches: a HIP event pair recorded INSIDE the graph
-(first and last node, on the launch stream), so that the graph's host-side launch latency -- which at K = 20 is a
-visible share of the wall clock -- is not billed to the kernel. The cpu_baseline leg times the CPU oracle (the C port of
+pass --no-graph for eager launches. roofline.frac has ONE definition, kept across rounds: algorithmic bytes / (HIP event
+pair on the launch stream around the timed region's own K launches / K). Two more readings of the same launches are
+reported beside it and never replace it: frac_wall (bytes / ms_per_step, the driver-visible clock) and
+frac_plain_launches (an event pair around K plain launches of the same call queued behind K untimed ones: no graph-replay
+fixed cost, no host launch latency). The cpu_baseline leg times the CPU oracle (the C port of
 the reference algorithm) on a bounded sample of the same workload, rank 0 at N = 1 only.
 
 One JSON line on stdout (rank 0).
@@ -38,7 +40,8 @@ STEP_BYTES_F32 = 46          # R board 16 + action 1 + score 4; W b
 STEP_BYTES_F64 = 50          # the same with the f64 reward (parity mode)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 BEAM_GAMES, BEAM_WIDTH, BEAM_DEPTH = 4096, 20, 30
-N_SIMD, CLOCK_GHZ = 1024, 2.4
+BEAM_BYTES_PER_EXPANSION = 29    # "HBM-resident-beam" accounting (parent 16 B / 4 children + child 16 + score 8 + root action 1)
+SIMDS_PER_CU = 4                 # MI355X_MICROARCH.md; the CU count and the clock come from the device properties
 
 
 def parse():
@@ -280,40 +283,29 @@ def main():
                 assert bool((gathered[r * n:(r + 1) * n] == vs).all()), "shard %d differs from the 1-GPU result" % r
 
     # ---- kernel time of the timed region's launches (after the score exchange above: the extra launches below add to `scores`)
-    timing = "HIP event pair on the launch stream around the K timed launches / K"
-    kernel_s = region_s = outer_ms * 1e-3 / K
-    if graph is not None and ev0 is not None:
-        try:
-            kernel_s = ev0.elapsed_time(ev1) * 1e-3 / K
-            timing = "HIP events recorded inside the hipGraph (first and last node, launch stream) around the K timed launches / K"
-        except Exception as exc:        # noqa: BLE001
-            print("bench.py: in-graph events unusable (%s)" % exc, file=sys.stderr)
-    else:
-        # torch on ROCm refuses timing events inside a capture ("External events are disallowed in rocm"), and an event pair
-        # around a graph replay bills the kernel for the replay's own fixed cost (~8 us per replay on MI355X: +0.4 us per
-        # launch at K = 20) and, from an idle stream, for the host's launch latency. So the kernel time is taken on plain
-        # launches: the same g2048_step call of the timed region (same buffers, same arguments), K times behind K untimed
-        # ones through a prepared call (ops.PreparedStep, ~4 us of host time per launch, so the GPU queue never runs
-        # dry), with the event pair around the second K. The pair around the timed region itself is reported too.
-        prepared = ops.PreparedStep(boards, actions, scores, SEED, id_base, out=out, reward=reward, flags=flags)
-        sp = torch.cuda.current_stream(dev).cuda_stream
-        best = None
-        for _ in range(3):
-            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for t in range(K):
-                prepared(W + t, sp)
-            q0.record()
-            for t in range(K):
-                prepared(W + t, sp)
-            q1.record()
-            torch.cuda.synchronize()
-            ms = q0.elapsed_time(q1)
-            best = ms if best is None else min(best, ms)
-        kernel_s = best * 1e-3 / K
-        timing = ("HIP event pair on the launch stream around K plain launches of the timed region's g2048_step call (same "
-                  "buffers and arguments) queued directly behind K untimed ones, / K; the pair around the timed region itself "
-                  "(one hipGraph replay from an idle stream: host launch latency and the replay's fixed cost included) gave "
-                  "%.3f us per launch" % (region_s * 1e6))
+    # THE definition of roofline.frac (frozen in round 3): the HIP event pair around the timed region's own K launches / K.
+    # With a hipGraph that pair also holds the replay's fixed cost (~8 us per replay: +0.4 us per launch at K = 20) and, from an
+    # idle stream, the host's launch latency -- so it under-reads the kernel; the two other readings below bracket it.
+    region_s = outer_ms * 1e-3 / K
+    kernel_s = region_s
+    timing = ("HIP event pair on the launch stream around the timed region's own K launches (one hipGraph replay unless "
+              "--no-graph), / K -- the definition roofline.frac keeps across rounds")
+    # plain launches: the same g2048_step call of the timed region (same buffers, same arguments), K times behind K untimed
+    # ones through a prepared call (ops.PreparedStep, ~4 us of host time per launch, so the GPU queue never runs dry)
+    prepared = ops.PreparedStep(boards, actions, scores, SEED, id_base, out=out, reward=reward, flags=flags)
+    sp = torch.cuda.current_stream(dev).cuda_stream
+    plain = []
+    for _ in range(3):
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for t in range(K):
+            prepared(W + t, sp)
+        q0.record()
+        for t in range(K):
+            prepared(W + t, sp)
+        q1.record()
+        torch.cuda.synchronize()
+        plain.append(q0.elapsed_time(q1) * 1e-3 / K)
+    plain_s, plain_mean_s = min(plain), sum(plain) / len(plain)
     # ---- roofline: algorithmic bytes per launch / average launch duration over the timed region ----
     achieved = n * STEP_BYTES_F32 / kernel_s / 1e9
     traffic = traffic_src = None
@@ -345,7 +337,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "step_kernel<false,false,1,256>", "kernel_us": kernel_s * 1e6,
-                     "kernel_us_timed_region_pair": region_s * 1e6,
+                     "frac_wall": n * STEP_BYTES_F32 / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+                     "frac_plain_launches": n * STEP_BYTES_F32 / plain_s / 1e9 / HBM_PEAK_GBS,
+                     "kernel_us_plain_launches": plain_s * 1e6, "kernel_us_plain_launches_mean_of_3": plain_mean_s * 1e6,
+                     "method_note": "round 2 reported frac from kernel_us_plain_launches (0.466); by this round's (frozen) "
+                                    "definition round 2 was 13.49 us = 0.447, round 1 14.63 us = 0.412",
                      "algorithmic_bytes_per_launch": n * STEP_BYTES_F32, "timing": timing,
                      "note": "LLC-resident working set at this size; the kernel is VALU-issue bound (DESIGN.md 3)"},
     }
@@ -390,11 +386,13 @@ def main():
                 ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
         big_steps()
         gb, ab, bb2 = (None, None, None) if args.no_graph else graph_of(big_steps, dev)
-        ms = timed_replay(gb, ab, bb2, big_steps, reps=4)
-        us = ms * 1e3 / KB
+        all_ms = [timed_replay(gb, ab, bb2, big_steps, reps=1) for _ in range(4)]
+        us = min(all_ms) * 1e3 / KB
+        us_mean = sum(all_ms) / len(all_ms) * 1e3 / KB
         result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
-                                           "kernel_us": us, "boards_per_launch": nb,
+                                           "frac_mean_of_4": nb * STEP_BYTES_F32 / us_mean / 1e3 / HBM_PEAK_GBS,
+                                           "kernel_us": us, "kernel_us_mean_of_4": us_mean, "boards_per_launch": nb,
                                            "traffic": (pmc_extra.get("hbm_resident_leg") or {}).get("hbm_bytes_per_launch"),
                                            "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
                                                              % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
@@ -428,6 +426,10 @@ def main():
         result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games)",
                           "value": total_exp / bsec, "unit": "expansions/s",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
+                          "gbs_equivalent_29B": total_exp / bsec * BEAM_BYTES_PER_EXPANSION / 1e9,
+                          "gbs_equivalent_29B_frac_of_hbm_peak": total_exp / bsec * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
+                          "gbs_equivalent_note": "SURVEY 8(d): 29 B per expansion if the beam lived in HBM; the search keeps it in LDS "
+                                                 "(16 B in, 5 B out per decision), so this is a comparability figure, not traffic",
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
                           "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
                                     "a bitonic network over the lanes; a 4.5 us beam_order_kernel deals the games to the SIMDs by depth "
@@ -440,11 +442,14 @@ def main():
             pj = json.load(open(pb))
             insts = float(pj["valu_wave_instructions_per_launch"])
             cyc = float(pj["issue_cycles_per_instruction"])
-            peak = N_SIMD * CLOCK_GHZ / cyc             # G wave-instructions / s
+            props = torch.cuda.get_device_properties(dev)
+            n_simd = props.multi_processor_count * SIMDS_PER_CU      # 256 CUs x 4 on MI355X; taken from the device
+            clock_ghz = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
+            peak = n_simd * clock_ghz / cyc             # G wave-instructions / s
             ach = insts / (bsec / breps) / 1e9
             result["beam"]["roofline"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
                                           "frac": ach / peak, "valu_wave_instructions_per_launch": insts,
-                                          "issue_cycles_per_instruction": cyc,
+                                          "issue_cycles_per_instruction": cyc, "simds": n_simd, "clock_ghz": clock_ghz,
                                           "source": "instruction count from a recorded rocprofv3 SQ_INSTS_VALU pass (%s); "
                                                     "time measured in this run" % pj.get("source", "profiles/pmc_beam.json")}
 
@@ -481,11 +486,32 @@ def main():
         except Exception as exc:                # noqa: BLE001
             result["evaluation_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
-    # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions
-    # drawn inside the step kernel (G2048_STEP_RANDOM_ACTIONS; realistic tile distribution instead of the synthetic
-    # one), auto-reset on; one hipGraph of 128 step launches
+    # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions,
+    # auto-reset on (realistic tile distribution instead of the synthetic one). g2048_step_many runs all 128 steps of a board
+    # in ONE launch with the board in registers (per-step f32 rewards streamed out, final boards / scores / flags); the
+    # 128-launch form (one hipGraph of g2048_step launches, each re-reading and re-writing 46 B per board) is timed beside it.
     if not args.no_rollout:
+        T_ROLL = 128
         rb, rs = ops.reset(n, SEED, 0, id_base, device=dev)
+        rstream = torch.empty((T_ROLL, n), dtype=torch.float32, device=dev)
+
+        def many(t0, stream):
+            ops.step_many(rb, rs, SEED, t0, T_ROLL, id_base, out=rb, flags=flags, auto_reset=True, reward_stream=stream)
+
+        def time_many(stream):
+            best = None
+            for rep in range(3):
+                m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                m0.record()
+                many(T_ROLL * (1 + rep), stream)
+                m1.record()
+                torch.cuda.synchronize()
+                ms = m0.elapsed_time(m1)
+                best = ms if best is None else min(best, ms)
+            return best
+        many(0, rstream)
+        torch.cuda.synchronize()
+        ms_stream, ms_bare = time_many(rstream), time_many(None)
 
         def rollout_steps(t0=128):
             for t in range(t0, t0 + 128):
@@ -495,8 +521,16 @@ def main():
         rg, ra, rbv = (None, None, None) if args.no_graph else graph_of(rollout_steps, dev)
         ms = timed_replay(rg, ra, rbv, rollout_steps, reps=2)
         result["rollout_random"] = {"metric": "board-steps/s, 1,048,576 boards x 128 consecutive in-place steps from reset, "
-                                              "uniform actions drawn in the kernel, auto-reset (realistic tile distribution)",
-                                    "value": n * 128 / (ms * 1e-3), "unit": "board-steps/s", "us_per_step": ms * 1e3 / 128}
+                                              "uniform actions drawn in the kernel, auto-reset (realistic tile distribution); "
+                                              "ONE g2048_step_many launch, boards in registers, per-step f32 rewards streamed out",
+                                    "value": n * T_ROLL / (ms_stream * 1e-3), "unit": "board-steps/s",
+                                    "us_per_step": ms_stream * 1e3 / T_ROLL,
+                                    "kernel": "step_many_kernel<false,true,256>",
+                                    "without_reward_stream": {"value": n * T_ROLL / (ms_bare * 1e-3), "us_per_step": ms_bare * 1e3 / T_ROLL,
+                                                              "note": "no per-step output requested: the shaped reward is not computed"},
+                                    "as_128_step_launches": {"value": n * 128 / (ms * 1e-3), "us_per_step": ms * 1e3 / 128,
+                                                             "note": "round 2's form: one hipGraph of 128 g2048_step launches"}}
+        del rstream
 
     # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
     if not args.no_rollout and world == 1:
@@ -572,14 +606,19 @@ def main():
         # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the box's CPU
         # share (16 for one GPU) or to the cores this process may run on, whichever is smaller
         many = min(16, info["affinity"])
-        p1, s1, _ = time_steps(1, args.cpu_seconds * 0.4)
-        passes, csec, (bo_, so_, ro_, fo_) = time_steps(many, args.cpu_seconds * 0.6)
+        every = min(info["affinity"], 512)      # all the host cores this process may run on ("1 core and all host cores")
+        p1, s1, _ = time_steps(1, args.cpu_seconds * 0.35)
+        pa, sa, _ = time_steps(every, args.cpu_seconds * 0.25) if every > many else (0, 1.0, None)
+        passes, csec, (bo_, so_, ro_, fo_) = time_steps(many, args.cpu_seconds * 0.4)
         result["cpu_baseline"] = {"value": n * passes / csec, "unit": "board-steps/s", "cores": O.num_threads(),
                                   "kind": "port",
                                   "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
                                             "(%.1f s, OpenMP static over boards)" % (passes, csec),
                                   "one_thread": {"value": n * p1 / s1, "cores": 1,
                                                  "sample": "%d passes, %.1f s" % (p1, s1)},
+                                  "all_affinity_cores": ({"value": n * pa / sa, "cores": every,
+                                                          "sample": "%d passes, %.1f s, one OpenMP thread per core in the affinity mask"
+                                                                    % (pa, sa)} if every > many else None),
                                   **info}
         from oracle import pyref
         prate = pyref.time_steps(4000, SEED)
@@ -604,13 +643,17 @@ def main():
                     cexp += int(last[2].sum()); cdec += 1
                 return cexp, cdec, time.perf_counter() - c0, last
             e1, d1, sec1, _ = time_beam(1, args.cpu_seconds * 0.3, 100)
-            cexp, cdec, csec, (oa, op, oe) = time_beam(many, args.cpu_seconds * 0.6, 100)
+            ea, da, seca, _ = time_beam(every, args.cpu_seconds * 0.3, 100) if every > many else (0, 0, 1.0, None)
+            cexp, cdec, csec, (oa, op, oe) = time_beam(many, args.cpu_seconds * 0.5, 100)
             result["beam"]["cpu_baseline"] = {"value": cexp / csec, "unit": "expansions/s",
                                               "cores": O.num_threads(), "kind": "port",
                                               "sample": "%d batch decisions over the same 4096 roots (%.1f s, OpenMP "
                                                         "dynamic over games)" % (cdec, csec),
                                               "one_thread": {"value": e1 / sec1, "cores": 1,
                                                              "sample": "%d batch decisions over the first 256 roots, %.1f s" % (d1, sec1)},
+                                              "all_affinity_cores": ({"value": ea / seca, "cores": every,
+                                                                      "sample": "%d batch decisions over the same 4096 roots, %.1f s"
+                                                                                % (da, seca)} if every > many else None),
                                               **info}
             a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
                                           game_id_base=0, want_expanded=True)

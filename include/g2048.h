@@ -10,9 +10,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. a
- *     torch.Tensor's data_ptr()); the library allocates nothing and never
- *     synchronises: work is enqueued on `stream` (a hipStream_t passed as
- *     void*, NULL = the default stream) and is stream-ordered;
+ *     torch.Tensor's data_ptr()); scratch is caller-provided too (the *_ws entry
+ *     points with their *_workspace queries). ONE entry point allocates:
+ *     g2048_play_games, the convenience form of g2048_play_games_ws, takes its
+ *     helper workspace from the stream-ordered pool (hipMallocAsync / hipFreeAsync
+ *     on `stream`). Nothing ever synchronises: work is enqueued on `stream` (a
+ *     hipStream_t passed as void*, NULL = the default stream) and is stream-ordered;
  *   - a board is 16 bytes: 16 x uint8 log2 codes, row-major (0 = empty,
  *     1 = tile 2, ... 17 = tile 131072). Board arrays must be 16-byte aligned;
  *   - return value: 0 = G2048_OK, negative = error (g2048_last_error() gives
@@ -21,7 +24,12 @@
  *     GLOBAL board id, counter): results do not depend on launch geometry or
  *     on how boards are sharded over GPUs (DESIGN.md "RNG");
  *   - thread-safe: no global mutable state apart from the thread-local error
- *     string.
+ *     string; no environment variable is read (round 2's G2048_PLAY_TUNE hook is
+ *     gone: g2048_play_games_tuned takes the same numbers as an argument);
+ *   - launch geometry that depends on the chip's size (how many helper wavefronts a
+ *     launch may carry, how a beam batch is dealt to the SIMDs) is derived per call
+ *     from the compute-unit count of the current device (g2048_launch_plan shows
+ *     the arithmetic).
  * There is no CPU implementation behind this ABI: without a HIP device every
  * compute entry point fails with G2048_ERR_HIP.
  */
@@ -33,7 +41,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 1
+#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan; no env hook) */
 
 enum {
     G2048_OK = 0,
@@ -212,6 +220,25 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
                         uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
                         uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/* g2048_play_games_ws with the helper-wavefront parameters given explicitly -- a measurement / test interface (the games are
+ * the same for every setting; only the time changes). tuning4 = { helper wavefronts (clamped to 8 per game and to the
+ * device's cap, g2048_launch_plan), games left at which every remaining game registers for helpers (>= n_games: at once),
+ * "stuck" threshold = invalid minus valid moves at which a game registers early (clamped to 1 .. 2^20), microseconds an
+ * owner polls for a posted result (clamped to 1000) }. The defaults g2048_play_games uses: { min(8 n, max(n / 4, 1024), cap),
+ * max(n / 8, 256), 16, 60 }. */
+int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
+                           int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
+                           uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
+                           uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
+                           size_t workspace_bytes, const uint32_t *tuning4, void *stream);
+
+/* The launch arithmetic the library derives from the device's size, as a pure host function (no launch, no allocation):
+ * out4 = { SIMD row length beam batches are dealt in (4 per compute unit), smallest batch that gets the depth-balanced
+ * order (four searches per SIMD), most helper wavefronts a g2048_play_games launch may carry (a quarter of the wavefronts
+ * the device holds at once: compute_units x resident_blocks_per_cu / 4), default helper wavefronts for n_games }.
+ * compute_units = 0: the current device's count; resident_blocks_per_cu = 0: 32 (the hardware cap for 64-thread blocks). */
+int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_games, uint32_t *out4);
 
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);

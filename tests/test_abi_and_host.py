@@ -34,8 +34,34 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), "symbol %s declared in include/g2048.h is not exported" % n
     assert set(names) == set(built.SIGNATURES), "python binding table and header disagree"
-    assert built.lib().g2048_abi_version() == 1
+    hdr = open(os.path.join(REPO, "include", "g2048.h")).read()
+    version = int(re.search(r"#define G2048_ABI_VERSION (\d+)", hdr).group(1))
+    assert version == 2 and built.lib().g2048_abi_version() == version == built.ABI_VERSION       # bumped whenever the entry points change
     assert built.lib().g2048_device_count() >= 0
+
+
+def test_launch_plan_arithmetic(built):
+    """The chip-size arithmetic (helper-wavefront cap, SIMD row length of the balanced beam order, smallest balanced batch)
+    as the library derives it from a compute-unit count: MI355X (256 CUs), a quarter partition (64), one XCD (32)."""
+    from g2048 import ops
+    full = ops.launch_plan(256, 32, 4096)
+    assert full == dict(order_row=1024, order_min_games=4096, helper_cap=2048, default_helpers=1024)      # rounds 1-2's constants
+    assert ops.launch_plan(256, 32, 16384)["default_helpers"] == 2048 and ops.launch_plan(256, 32, 100)["default_helpers"] == 800
+    q = ops.launch_plan(64, 32, 4096)
+    assert q == dict(order_row=256, order_min_games=1024, helper_cap=512, default_helpers=512)
+    x = ops.launch_plan(32, 32, 4096)
+    assert x == dict(order_row=128, order_min_games=512, helper_cap=256, default_helpers=256)
+    assert ops.launch_plan(256, 9, 4096)["helper_cap"] == 576           # width > 64 searches: ~9 resident blocks per CU (17 KB of LDS each)
+    assert ops.launch_plan(1, 1, 1)["helper_cap"] == 1                  # never zero
+    for cus in (32, 64, 256, 304):
+        p = ops.launch_plan(cus, 32, 0)
+        assert p["order_row"] == 4 * cus and p["order_min_games"] == 4 * p["order_row"] and p["helper_cap"] == 8 * cus
+    L = built.lib()
+    assert L.g2048_launch_plan(-1, 0, 0, None) == -1
+    # the library reads no environment variable (round 2's G2048_PLAY_TUNE hook is gone)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", built.library_path()], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_argument_validation_without_device(built):

@@ -184,12 +184,13 @@ def test_speculative_helpers_play_the_same_games(g2048, n, w, d, cap, fixed_down
 
 
 def test_speculative_helpers_tuning_extremes(g2048, monkeypatch):
-    """No helper at all, helpers that are always late (0 us wait) and eager registration give the same games."""
+    """No helper at all, helpers that are always late (0 us wait) and eager registration give the same games (explicit
+    tuning through g2048_play_games_tuned; out-of-range values are clamped; the library reads no environment variable)."""
     kw = dict(num_games=96, beam_width=12, search_depth=8, seed=99, max_moves=1200)
     r0 = g2048.evaluate_beam_search(one_phase=True, **kw)
-    for tune in ("0,256,16,60", "384,256,16,0", "64,1000000,1,200", "2048,0,1000000,60"):
-        monkeypatch.setenv("G2048_PLAY_TUNE", tune)
-        r1 = g2048.evaluate_beam_search(**kw)
+    monkeypatch.setenv("G2048_PLAY_TUNE", "0,0,0,0")      # round 2's hook: must be ignored now
+    for tune in ((0, 256, 16, 60), (384, 256, 16, 0), (64, 1000000, 1, 200), (2048, 0, 1000000, 60), (1 << 31, 7, 0, 1 << 31)):
+        r1 = g2048.evaluate_beam_search(tuning=tune, **kw)
         for k in PLAY_KEYS:
             assert r0[k] == r1[k], (tune, k)
         assert np.array_equal(r0["final_boards"], r1["final_boards"])

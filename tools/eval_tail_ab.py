@@ -1,5 +1,5 @@
 """A/B of the evaluation driver's speculative helpers (g2048_play_games): same games, time per variant.
-usage: python tools/eval_tail_ab.py [games] [width] [depth]"""
+usage: python tools/eval_tail_ab.py [games] [width] [depth] ["helpers,games_left,stuck,wait_us;..."]   (explicit tunings go through g2048_play_games_tuned)"""
 import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,12 +17,10 @@ variants = [("one wavefront per game", None), ("helpers, defaults", "")]
 for spec in (sys.argv[4].split(";") if len(sys.argv) > 4 else []):
     variants.append((spec, spec))
 for name, tune in variants:
-    os.environ.pop("G2048_PLAY_TUNE", None)
-    if tune:
-        os.environ["G2048_PLAY_TUNE"] = tune
+    tuning = tuple(int(x) for x in tune.split(",")) if tune else None      # "helpers,games_left,stuck,wait_us"
     best = None
     for rep in range(2):
-        r = g2048.evaluate_beam_search(n, w, d, seed=2025, one_phase=tune is None)
+        r = g2048.evaluate_beam_search(n, w, d, seed=2025, one_phase=tune is None, tuning=tuning)
         best = r["elapsed_s"] if best is None else min(best, r["elapsed_s"])
     sig = (tuple(r["scores"]), tuple(r["moves"]), tuple(r["invalid_moves"]), tuple(r["highest_tiles"]), r["total_expansions"])
     if base is None:

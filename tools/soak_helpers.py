@@ -27,11 +27,8 @@ while time.time() - t0 < budget:
               game_id_base=rnd.getrandbits(35), fixed_down=rnd.random() < 0.25)
     tune = rnd.choice([None, None, "%d,%d,%d,%d" % (rnd.choice([0, 8, 64, 512, 2048]), rnd.choice([0, 16, 256, 100000]),
                                                     rnd.choice([1, 4, 16, 64]), rnd.choice([0, 5, 60, 300]))])
-    os.environ.pop("G2048_PLAY_TUNE", None)
     r0 = g2048.evaluate_beam_search(one_phase=True, **kw)
-    if tune:
-        os.environ["G2048_PLAY_TUNE"] = tune
-    r1 = g2048.evaluate_beam_search(**kw)
+    r1 = g2048.evaluate_beam_search(tuning=tuple(int(x) for x in tune.split(",")) if tune else None, **kw)
     ok = all(r0[k] == r1[k] for k in KEYS) and np.array_equal(r0["final_boards"], r1["final_boards"])
     runs += 1
     if not ok:
