@@ -76,6 +76,8 @@ class BeamSearchAgent:
             f.write(f"Beam Width: {self.beam_width}\nSearch Depth: {self.search_depth}\n")
             f.write(f"Early Game Threshold: {self.early_game_threshold}\nMid Game Threshold: {self.mid_game_threshold}\n")
             f.write(f"\nSaved at: {path}\n")
+            f.write("\nThis configuration achieved good results in training.\n")
+            f.write("To recreate this agent, use:\n")
             f.write(f"agent = BeamSearchAgent(beam_width={self.beam_width}, search_depth={self.search_depth})")
 
     @classmethod

@@ -824,6 +824,28 @@ G2048_HD double eval_full_known(const Board &b, uint32_t phase, uint32_t e, uint
     return (((empty_score + max_score) + corner_bonus) + mp) + snake;
 }
 
+// Game2048Env._evaluate_pattern (environment/game_2048.py:313-339; no caller in the reference): max of two weighted sums of
+// the real tile values, each / 100.0 -- the snake weights 16..1 and the corner weights 16, 8, 4, ... 0.25. Every product and
+// every partial sum is an exact binary fraction far below 2^53 whatever order numpy adds them in, so the corner sum is taken
+// four times as large in integers (weights 64 .. 1) and scaled by 0.25; one rounding each: the division by 100.0.
+G2048_HD double eval_pattern(const Board &b)
+{
+    uint32_t snake = 0, corner4 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t code = (b.w[r] >> (8 * c)) & 0xffu;
+            const uint32_t tile = code ? (1u << code) : 0u;
+            const uint32_t ws = r == 0 ? 16u - c : r == 1 ? 9u + c : r == 2 ? 8u - c : 1u + c;        // :319-324
+            snake += tile * ws;
+            corner4 += tile << (6 - r - c);                                                          // :327-332, times 4
+        }
+    }
+    const double s = (double)snake / 100.0, k = ((double)corner4 * 0.25) / 100.0;                   // :335-336
+    return s > k ? s : k;                                                                            // :339
+}
+
 // agents/beam_search_agent.py:271-278 with thresholds as tile values
 G2048_HD uint32_t phase_of(uint32_t maxcode, uint32_t early_thr, uint32_t mid_thr)
 {

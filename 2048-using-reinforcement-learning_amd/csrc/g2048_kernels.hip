@@ -340,6 +340,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ 
     else if (KIND == G2048_EVAL_FULL) v = eval_full(b, phase ? (uint32_t)phase[i] : phase_of(max_code(b), 512u, 1024u));
     else if (KIND == G2048_EVAL_PPO_HEURISTIC) v = eval_ppo_heuristic(b);
     else if (KIND == G2048_EVAL_PPO_SHAPING) v = eval_ppo_shaping(b, 0.0);
+    else if (KIND == G2048_EVAL_PATTERN) v = eval_pattern(b);
     else v = eval_monotonicity(b, KIND - G2048_EVAL_MONO_PP);
     out[i] = v;
 }
@@ -738,6 +739,7 @@ int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, doubl
         G2048_EVAL_CASE(G2048_EVAL_MONO_MP)
         G2048_EVAL_CASE(G2048_EVAL_MONO_MM)
         G2048_EVAL_CASE(G2048_EVAL_PPO_SHAPING)
+        G2048_EVAL_CASE(G2048_EVAL_PATTERN)
 #undef G2048_EVAL_CASE
         default: return fail(G2048_ERR_ARG, "g2048_eval: unknown kind %d", kind);
     }

@@ -128,6 +128,9 @@ class Game2048Env:
     def is_game_over(self):                                    # reference :279-288
         return not any(self.get_valid_moves())
 
+    def _evaluate_pattern(self):                               # reference :313-339 (no caller there; kept for the API)
+        return float(ops.evaluate(self._boards, L.EVAL_PATTERN).item())
+
     def render(self, mode="human"):                            # reference :290-311 (host-side text)
         if mode == "human":
             print("-" * (5 * self.size + 1))

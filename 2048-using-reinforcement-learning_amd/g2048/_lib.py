@@ -18,7 +18,7 @@ ABI_VERSION = 2
 FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
 STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS, STEP_NOOP_ACTIONS = 0x01, 0x02, 0x04, 0x08
 VALID_ENV, VALID_AGENT = 0, 1
-EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING = range(8)
+EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING, EVAL_PATTERN = range(9)
 BEAM_FIXED_DOWN = 0x01
 BEAM_RANK_BY_COUNTING = 0x04
 PLAY_ONE_PHASE = 0x02

@@ -320,33 +320,53 @@ class SeenStates:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.highest = torch.ones(1, dtype=torch.int32, device=self.device)     # log2 code of tile 2 (ppo_agent.py:171)
         self.index = 0              # transitions presented so far (global order)
+        self._count_bound = 0       # host-side upper bound of the number of keys in the table (see reserve)
 
     def reserve(self, n_new):
-        """Grow (rehash into a zeroed table twice the size, repeatedly) until count + n_new keys keep it at most half
-        full. Reads the key count back from the device (one host sync)."""
-        if int(self.overflow.item()):
-            raise RuntimeError("g2048: the seen-states table overflowed (it is sized by reserve(); was it bypassed?)")
-        need = int(self.count.item()) + int(n_new)
-        log2 = self.capacity_log2
-        while (1 << log2) < 2 * need:
-            log2 += 1
-        if log2 != self.capacity_log2:
+        """Make room for n_new more transitions without overflowing: the table is kept at most half full of the keys it
+        COULD hold. The host tracks an upper bound of the key count (the last count read back + every transition presented
+        since); only when that bound no longer fits does it read the true count back (the one host sync, also the point where
+        the overflow flag is looked at) and, if needed, grow by rehashing into a zeroed table with twice the room required --
+        so in the steady state of a long run (many more keys than transitions per batch) batches are enqueued without any
+        host round trip."""
+        n_new = int(n_new)
+        if 2 * (self._count_bound + n_new) <= (1 << self.capacity_log2):
+            self._count_bound += n_new
+            return
+        self.assert_ok()                                    # host sync: overflow flag ...
+        count = int(self.count.item())                      # ... and the true key count
+        need = count + n_new
+        if 2 * need > (1 << self.capacity_log2):
+            log2 = self.capacity_log2
+            while (1 << log2) < 4 * need:                   # twice the room needed now: the next batches fit under the bound
+                log2 += 1
             if log2 > 31:
                 raise RuntimeError("g2048: seen-states table would exceed 2^31 slots")
             new = torch.zeros((1 << log2, L.SEEN_SLOT_BYTES), dtype=torch.uint8, device=self.device)
             L.call(self.device, L.lib().g2048_seen_rehash, self.table.data_ptr(), self.capacity_log2, new.data_ptr(), log2,
                    self.overflow.data_ptr(), L.stream_ptr(self.device))
             self.table, self.capacity_log2 = new, log2
+        self._count_bound = need
+
+    def assert_ok(self):
+        """Raise if an insert ever found the table full or gave up probing (host sync). reserve() makes that impossible for
+        batches that go through remember_shaping; call this after the LAST batch of a run, or pass check=True there."""
+        flag = int(self.overflow.item())
+        if flag:
+            raise RuntimeError("g2048: the seen-states table overflowed (flag 0x%x): novelty terms of the batches since the last "
+                               "check are not trustworthy -- it is sized by reserve(); was it bypassed?" % flag)
 
     def __len__(self):
         return int(self.count.item())
 
 
-def remember_shaping(seen, next_boards, state_maxcode, flags, env_reward, out=None, want_novel=False):
+def remember_shaping(seen, next_boards, state_maxcode, flags, env_reward, out=None, want_novel=False, check=False):
     """PPOAgent.remember's stored reward (agents/ppo_agent.py:234-269) for an ORDERED batch of transitions, with the
     reference's sequential semantics for both stateful terms, continuing from `seen` (a SeenStates). Inputs are flat in
     order: next_boards uint8 (n,16) -- the next state BEFORE any auto-reset --, state_maxcode uint8 (n,), flags uint8 (n,)
-    as the step wrote them, env_reward float64 (n,). Returns shaped float64 (n,) [, novel uint8 (n,)]."""
+    as the step wrote them, env_reward float64 (n,). Returns shaped float64 (n,) [, novel uint8 (n,)]. check=True reads the
+    table's overflow flag back after THIS batch (one host sync) and raises if it is set; without it the flag is looked at
+    the next time the table has to be re-sized, or by seen.assert_ok()."""
     L.require_device_tensor(next_boards, torch.uint8, (16,), "next_boards")
     n, dev = next_boards.shape[0], next_boards.device
     L.require_device_tensor(state_maxcode, torch.uint8, None, "state_maxcode")
@@ -376,6 +396,8 @@ def remember_shaping(seen, next_boards, state_maxcode, flags, env_reward, out=No
            prev_highest.data_ptr(), seen.table.data_ptr(), slots.data_ptr(), L.u64(seen.index), out.data_ptr(),
            novel.data_ptr() if novel is not None else None, n, st)
     seen.index += n
+    if check:
+        seen.assert_ok()
     return (out, novel) if want_novel else out
 
 

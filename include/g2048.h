@@ -83,8 +83,9 @@ enum {
     G2048_EVAL_MONO_PM = 4,    /*                        (+1, -1) */
     G2048_EVAL_MONO_MP = 5,    /*                        (-1, +1) */
     G2048_EVAL_MONO_MM = 6,    /*                        (-1, -1) */
-    G2048_EVAL_PPO_SHAPING = 7 /* the pure per-transition terms of PPOAgent.remember, ppo_agent.py:253-266:
+    G2048_EVAL_PPO_SHAPING = 7,/* the pure per-transition terms of PPOAgent.remember, ppo_agent.py:253-266:
                                   0.1 * sum(log2(top-4 tiles)) + 0.3 * evaluate_heuristic (stateful terms excluded) */
+    G2048_EVAL_PATTERN = 8     /* Game2048Env._evaluate_pattern  game_2048.py:313-339 (snake / corner weights on tile values) */
 };
 
 /* opts of g2048_beam_get_action */

@@ -976,6 +976,20 @@ void g2048o_valid_moves_batch(const uint8_t *boards, uint8_t *mask4, size_t n, i
 
 /* kind: 0 fast, 1 full (phase[i] in 0..2), 2 ppo heuristic, 3..6 monotonicity
  * (+,+) (+,-) (-,+) (-,-), 7 pure PPO shaping terms (reward_in = 0).          */
+/* environment/game_2048.py:313-339 (_evaluate_pattern; unused by the reference itself): np.sum(board * snake) / 100.0 and
+ * np.sum(board * corner) / 100.0 -- the int products summed in int64, the float products (weights down to 0.25: exact binary
+ * fractions, so numpy's pairwise order and this sequential one give the same sum) in float64 -- then max(). */
+double g2048o_pattern(const int32_t b[16])
+{
+    static const int32_t snake[16] = {16, 15, 14, 13, 9, 10, 11, 12, 8, 7, 6, 5, 1, 2, 3, 4};                    /* :319-324 */
+    static const double corner[16] = {16, 8, 4, 2, 8, 4, 2, 1, 4, 2, 1, 0.5, 2, 1, 0.5, 0.25};                   /* :327-332 */
+    int64_t s = 0;
+    double c = 0.0;
+    for (int i = 0; i < 16; ++i) { s += (int64_t)b[i] * snake[i]; c += (double)b[i] * corner[i]; }
+    const double snake_score = (double)s / 100.0, corner_score = c / 100.0;                                      /* :335-336 */
+    return snake_score > corner_score ? snake_score : corner_score;                                              /* :339 */
+}
+
 void g2048o_eval_batch(const uint8_t *boards, int kind, const uint8_t *phase, double *out, size_t n)
 {
 #pragma omp parallel for schedule(static)
@@ -991,6 +1005,7 @@ void g2048o_eval_batch(const uint8_t *boards, int kind, const uint8_t *phase, do
         case 4: v = g2048o_monotonicity(b, 1, -1); break;
         case 5: v = g2048o_monotonicity(b, -1, 1); break;
         case 6: v = g2048o_monotonicity(b, -1, -1); break;
+        case 8: v = g2048o_pattern(b); break;
         default: v = g2048o_ppo_shaping(b, 0.0); break;
         }
         out[i] = v;

@@ -69,6 +69,7 @@ int    g2048o_agent_valid_mask(const int32_t b[16]);                            
 int    g2048o_phase(int32_t max_tile, int32_t early_thr, int32_t mid_thr);       /* :271-278 */
 double g2048o_fast_eval(const int32_t b[16]);                                    /* :280-314 */
 double g2048o_full_eval(const int32_t b[16], int phase);                         /* :316-373 */
+double g2048o_pattern(const int32_t b[16]);                                      /* environment/game_2048.py:313-339 */
 /* get_action (:71-181). draws: explicit stream (may be NULL -> hashed from
  * (seed, step_index, game_id, counter)). valid_mask4 < 0 means "None".
  * trace_scores[(depth)*width] / trace_counts[depth] optional (NULL ok).     */

@@ -652,9 +652,59 @@ def gen_simulate_sampled():
                         done=done, count=count, seed=np.uint64(SEED), step_index=np.uint64(3))
 
 
+def gen_pattern():
+    """Game2048Env._evaluate_pattern (environment/game_2048.py:313-339; nobody in the reference calls it) on the boards of
+    eval_scores.npz."""
+    pool = np.load(os.path.join(HERE, "eval_scores.npz"))["board"]
+    env = Game2048Env()
+    out = np.zeros(pool.shape[0], np.float64)
+    for i in range(pool.shape[0]):
+        set_env(env, tiles_of(pool[i]))
+        out[i] = env._evaluate_pattern()
+    np.savez_compressed(os.path.join(HERE, "pattern.npz"), board=pool, pattern=out)
+    print("pattern", pool.shape[0])
+
+
+def gen_checkpoint():
+    """The beam agent's checkpoint format (agents/beam_search_agent.py:413-478): the text of the reference-held
+    checkpoints/BeamSearchAgent_*.pth files (JSON despite the name) and README files, and what the reference's own
+    load() -> save() writes for each of them (JSON + README), saved under the same relative path from a scratch directory."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    ck = os.path.join(REF, "checkpoints")
+    out = {"files": {}, "resaved": {}}
+    for name in sorted(os.listdir(ck)):
+        if (name.startswith("BeamSearchAgent") and name.endswith(".pth")) or name.startswith("beam_search_config_readme"):
+            out["files"][name] = open(os.path.join(ck, name)).read()
+    here = os.getcwd()
+    for name in [n for n in out["files"] if n.endswith(".pth")]:
+        with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+            try:
+                os.chdir(tmp)
+                agent = BeamSearchAgent.load(os.path.join(ck, name))
+                rel = os.path.join("checkpoints", name)
+                agent.save(rel)
+                readme = "beam_search_config_readme_%d_%d.txt" % (agent.beam_width, agent.search_depth)
+                out["resaved"][name] = {"path": rel, "json": open(rel).read(), "readme_name": readme,
+                                        "readme": open(os.path.join("checkpoints", readme)).read(),
+                                        "beam_width": agent.beam_width, "search_depth": agent.search_depth,
+                                        "early_game_threshold": agent.early_game_threshold,
+                                        "mid_game_threshold": agent.mid_game_threshold}
+            finally:
+                os.chdir(here)
+    with open(os.path.join(HERE, "beam_checkpoint.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("beam_checkpoint", sorted(out["files"]))
+
+
 def main():
     if "--only" in sys.argv:
         what = sys.argv[sys.argv.index("--only") + 1]
+        if what in ("pattern", "checkpoint"):
+            {"pattern": gen_pattern, "checkpoint": gen_checkpoint}[what]()
+            return
         if what == "step_noop":
             rng = np.random.default_rng(1)
             gen_step_noop(np.concatenate([random_code_boards(rng, 600, 0.30, 11), random_code_boards(rng, 300, 0.0, 3),
@@ -721,6 +771,8 @@ def main():
     rng2 = np.random.default_rng(1)
     gen_step_noop(np.concatenate([random_code_boards(rng2, 600, 0.30, 11), random_code_boards(rng2, 300, 0.0, 3),
                                   random_code_boards(rng2, 300, 0.6, 17)]).astype(np.uint8))
+    gen_pattern()
+    gen_checkpoint()
     print("done in %.1fs" % (time.time() - t0))
 
 

@@ -100,7 +100,8 @@ void hs_eval(const uint8_t *in, int kind, const uint8_t *phase, double *out, siz
         const Board b = ld(in + 16 * i);
         out[i] = kind == 0 ? eval_fast(b)
                : kind == 1 ? eval_full(b, phase ? phase[i] : phase_of(max_code(b), 512u, 1024u))
-               : kind == 2 ? eval_ppo_heuristic(b) : kind == 7 ? eval_ppo_shaping(b, 0.0) : eval_monotonicity(b, kind - 3);
+               : kind == 2 ? eval_ppo_heuristic(b) : kind == 7 ? eval_ppo_shaping(b, 0.0) : kind == 8 ? eval_pattern(b)
+               : eval_monotonicity(b, kind - 3);
     }
 }
 

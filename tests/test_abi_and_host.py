@@ -120,6 +120,31 @@ def test_missing_library_is_loud(built, monkeypatch, tmp_path):
         _lib.lib()
 
 
+def test_beam_agent_checkpoint_bytes_equal_the_reference(built, tmp_path, monkeypatch, capsys):
+    """tests/golden/beam_checkpoint.json holds the text of the reference's own checkpoints/BeamSearchAgent_*.pth files (JSON)
+    and of what the reference's load() -> save() writes for each (JSON + README, agents/beam_search_agent.py:413-478):
+    load() of the reference-held file, then save() under the same relative path, must produce the same bytes."""
+    from agents.beam_search_agent import BeamSearchAgent
+    fx = json.load(open(os.path.join(REPO, "tests", "golden", "beam_checkpoint.json")))
+    assert "BeamSearchAgent_final_model.pth" in fx["files"] and len(fx["resaved"]) >= 3
+    for name, want in fx["resaved"].items():
+        src = tmp_path / ("ref_" + name)
+        src.write_text(fx["files"][name])
+        a = BeamSearchAgent.load(str(src))
+        assert (a.beam_width, a.search_depth, a.early_game_threshold, a.mid_game_threshold) == (
+            want["beam_width"], want["search_depth"], want["early_game_threshold"], want["mid_game_threshold"])
+        work = tmp_path / ("w_" + name)
+        work.mkdir()
+        monkeypatch.chdir(work)
+        a.save(want["path"])
+        assert open(want["path"]).read() == want["json"] == fx["files"][name]
+        assert open(os.path.join("checkpoints", want["readme_name"])).read() == want["readme"]
+    # the README the reference shipped next to its final model is what save() writes for that model
+    assert fx["files"]["beam_search_config_readme_15_30.txt"] == fx["resaved"]["BeamSearchAgent_final_model.pth"]["readme"]
+    out = capsys.readouterr().out
+    assert "Beam Search configuration loaded from" in out and "Beam Search configuration saved to" in out
+
+
 def test_beam_agent_save_load_roundtrip(built, tmp_path, capsys):
     """JSON keys as the reference writes them (agents/beam_search_agent.py:420-425)."""
     from agents.beam_search_agent import BeamSearchAgent

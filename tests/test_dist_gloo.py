@@ -112,6 +112,44 @@ def test_two_rank_gloo_evaluation_table_gather():
     assert np.array_equal(got, full)
 
 
+def _empty_shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, PKG)
+    from g2048 import dist as gdist
+    from g2048.evaluate import TABLE_COLUMNS
+    gdist.init("gloo", torch.device("cpu"))
+    lo, hi = gdist.shard(1, rank, world)                        # ONE game for two ranks: a rank's shard is empty
+    full = np.arange(TABLE_COLUMNS, dtype=np.int64)[None, :] + 7
+    got = gdist.all_gather_rows(torch.from_numpy(full[lo:hi].copy()))
+    gdist.barrier()
+    q.put((rank, lo, hi, got.numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_with_an_empty_shard():
+    """Fewer games than ranks (evaluate_beam_search_sharded with num_games < world size): the rank whose shard is empty still
+    takes part in the gather, and every rank ends up with the whole table."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=120) for _ in range(2)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    sizes = sorted(hi - lo for _, lo, hi, _ in res)
+    assert sizes == [0, 1]
+    for _, _, _, got in res:
+        assert got.shape[0] == 1 and int(got[0, 0]) == 7
+    for p in procs:
+        assert p.exitcode == 0
+
+
 def test_results_from_table_is_the_single_process_result():
     """results_from_table over concatenated shard tables == over the whole table (the merge is a concatenation)."""
     sys.path.insert(0, PKG)

@@ -187,6 +187,14 @@ def test_eval_kernels(ops, oracle):
     assert np.array_equal(host(ops.evaluate(big, L.EVAL_PPO_HEURISTIC)), oracle.eval_batch(hb, oracle.EVAL_PPO))
     assert np.array_equal(host(ops.evaluate(big, L.EVAL_PPO_SHAPING)), oracle.eval_batch(hb, oracle.EVAL_PPO_SHAPING))
     assert np.array_equal(host(ops.obs(big)), oracle.obs_batch(hb))
+    gp = load_golden("pattern.npz")                     # Game2048Env._evaluate_pattern (game_2048.py:313-339), f64 ==
+    assert np.array_equal(host(ops.evaluate(dev(gp["board"]), L.EVAL_PATTERN)), gp["pattern"])
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_PATTERN)), oracle.eval_batch(hb, oracle.EVAL_PATTERN))
+    from environment.game_2048 import Game2048Env       # ... and through the drop-in class
+    env = Game2048Env(seed=3)
+    for i in (0, 17, 400, 2999):
+        env.board = tiles_of(gp["board"][i]).reshape(4, 4)
+        assert env._evaluate_pattern() == gp["pattern"][i]
 
 
 def test_pack_unpack_roundtrip(ops, oracle):

@@ -117,7 +117,17 @@ def test_two_rank_sharded_evaluation_equals_one_process(tmp_path):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
-    outs = [p.communicate(timeout=280) for p in procs]
+    try:
+        outs = [p.communicate(timeout=280) for p in procs]
+    finally:                                    # a stalled rank (rendezvous / barrier mismatch) must not keep the card
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so[-2000:] + se[-4000:]
     assert "sharded ok" in outs[0][0]

@@ -120,6 +120,48 @@ def test_remember_shaping_golden(g2048, oracle):
     assert seen.index == n and int(seen.overflow.item()) == 0
 
 
+def test_seen_states_overflow_is_reported_and_batches_need_no_sync(g2048, oracle):
+    """(1) A table that is too small for what it is given (reserve() bypassed: g2048_seen_insert called directly) sets the
+    overflow flag, and the flag is reported -- by assert_ok(), by remember_shaping(check=True) for the batch itself, and at
+    the next re-sizing. (2) Once the table has room under the host-side bound, further batches read nothing back."""
+    from g2048 import ops, _lib as L
+    n = 4096
+    boards = ops.synth_boards(n, seed=31, device=DEV, p_empty=0.3, max_code=11)
+    seen = ops.SeenStates(DEV, capacity_log2=6)                      # 64 slots for ~4096 distinct keys
+    slots = torch.empty(n, dtype=torch.int32, device=DEV)
+    L.call(seen.device, L.lib().g2048_seen_insert, boards.data_ptr(), 0, seen.table.data_ptr(), seen.capacity_log2,
+           seen.count.data_ptr(), seen.overflow.data_ptr(), slots.data_ptr(), n, L.stream_ptr(seen.device))
+    assert int(seen.overflow.item()) != 0 and bool((slots == -1).any())          # slot 0xffffffff = "not stored"
+    with pytest.raises(RuntimeError, match="overflowed"):
+        seen.assert_ok()
+    mx = boards.max(dim=1).values.contiguous()                       # state = next state here: its max code, and the flags byte
+    fl = (mx << 3).contiguous()                                      # a step would have written for it
+    rw = torch.zeros(n, dtype=torch.float64, device=DEV)
+    with pytest.raises(RuntimeError, match="overflowed"):                         # the re-sizing point looks at the flag
+        ops.remember_shaping(seen, boards, mx, fl, rw)
+    # (2) a fresh set: the first batches size the table (host syncs), later ones fit under the bound and enqueue only
+    seen = ops.SeenStates(DEV, capacity_log2=4)
+    R = oracle.Remember()
+    hb = boards.cpu().numpy()
+    calls = {"n": 0}
+    real = torch.Tensor.item
+    def counting_item(self):
+        calls["n"] += 1
+        return real(self)
+    for rep in range(6):
+        torch.Tensor.item = counting_item
+        try:
+            got = ops.remember_shaping(seen, boards, mx, fl, rw, check=(rep == 5))
+        finally:
+            torch.Tensor.item = real
+        want, _ = R.batch(hb, hb, np.zeros(n))
+        assert np.array_equal(got.cpu().numpy(), want)
+        if rep in (3, 4):
+            assert calls["n"] == 0, "a batch that fits under the host-side bound must not read anything back"
+        calls["n"] = 0
+    assert len(seen) == R.n_seen
+
+
 def test_remember_shaping_large_ordered_batch(g2048, oracle):
     """1.2 M transitions with heavy repetition (65,536 distinct boards): first-occurrence-in-order and the running
     maximum are exact for a batch far larger than a wave / a block / a scan tile."""

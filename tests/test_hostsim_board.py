@@ -174,6 +174,9 @@ def test_eval_vs_golden_and_oracle(hs, oracle):
     assert np.array_equal(ev(b, 7), g["ppo_shaping"])
     rb = random_boards(60000, 11)
     assert np.array_equal(ev(rb, 7), oracle.eval_batch(rb, oracle.EVAL_PPO_SHAPING))
+    gp = load_golden("pattern.npz")                 # Game2048Env._evaluate_pattern (integer formulation vs the reference's floats)
+    assert np.array_equal(ev(np.ascontiguousarray(gp["board"]), 8), gp["pattern"])
+    assert np.array_equal(ev(rb, 8), oracle.eval_batch(rb, oracle.EVAL_PATTERN))
     assert np.array_equal(ev(rb, 0), oracle.eval_batch(rb, oracle.EVAL_FAST))
     for ph in range(3):
         pa = np.full(rb.shape[0], ph, np.uint8)

@@ -100,6 +100,8 @@ def test_eval_scores(oracle):
     for k in range(4):
         assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_MONO_PP + k), g["monotonicity"][:, k])
     assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_PPO_SHAPING), g["ppo_shaping"])       # remember() pure terms
+    gp = load_golden("pattern.npz")                                                              # Game2048Env._evaluate_pattern
+    assert np.array_equal(oracle.eval_batch(gp["board"], oracle.EVAL_PATTERN), gp["pattern"])
     assert np.array_equal(oracle.obs_batch(b).view(np.uint32), g["normalize"].view(np.uint32))   # f32 bits
     for i in range(0, b.shape[0], 50):
         t = tiles_of(b[i])
