@@ -336,7 +336,7 @@ class SeenStates:
         self.assert_ok()                                    # host sync: overflow flag ...
         count = int(self.count.item())                      # ... and the true key count
         need = count + n_new
-        if 2 * need > (1 << self.capacity_log2):
+        if 2 * (need + n_new) > (1 << self.capacity_log2):      # (room for one more batch like this one under the bound, too)
             log2 = self.capacity_log2
             while (1 << log2) < 4 * need:                   # twice the room needed now: the next batches fit under the bound
                 log2 += 1
