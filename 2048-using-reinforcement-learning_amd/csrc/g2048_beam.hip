@@ -701,6 +701,30 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             continue;
         }
 #endif
+#ifndef G2048_BEAM_NO_SINGLE
+        // the same for a fast level with 17..64 children: one stream, the 64-key network, hand-over by slots
+        if (PASSES <= 2 && fast && !count_rank && total_valid > 16u && total_valid <= 64u) {
+            const bool live0 = lane < total_valid;
+            const uint4 cv0 = s_cboard[live0 ? lane : 0u];
+            const uint32_t cr0 = s_croot[live0 ? lane : 0u];
+            Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}};
+            const uint32_t nm0 = count_empty(c0);
+            const unsigned long long b0 = __ballot(live0 && nm0 != 0u);
+            spawn(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));          // :155 (a no-op on a full board)
+            draws += (uint32_t)__popcll(b0);
+            const uint32_t pm0 = cr0 >> 8;
+            const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
+            const uint32_t e0 = (eval_fast_u32_known(c0, nm0 - (nm0 ? 1u : 0u), cm0) << 9) + (511u - lane);
+            if (live0) {
+                s_cboard[lane] = make_uint4(c0.w[0], c0.w[1], c0.w[2], c0.w[3]);
+                s_croot[lane] = (cr0 & 0xffu) | (cm0 << 8);
+            }
+            pick = 511u - (sort_stages<64>(live0 ? e0 : 0u) & 511u);
+            nb = (int)min(total_valid, (uint32_t)width);
+            from_pick = true;
+            continue;
+        }
+#endif
         from_pick = false;
         const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u) && !(count_rank && fast);
         Board child[PASSES];

@@ -500,16 +500,17 @@ def main():
 
         def time_many(stream):
             best = None
-            for rep in range(3):
+            for rep in range(5):
                 m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 m0.record()
-                many(T_ROLL * (1 + rep), stream)
+                many(T_ROLL * (3 + rep), stream)
                 m1.record()
                 torch.cuda.synchronize()
                 ms = m0.elapsed_time(m1)
                 best = ms if best is None else min(best, ms)
             return best
-        many(0, rstream)
+        for w in range(3):                      # untimed: first-touch of the 512 MB reward stream, clocks to steady state
+            many(w * T_ROLL, rstream)
         torch.cuda.synchronize()
         ms_stream, ms_bare = time_many(rstream), time_many(None)
 
