@@ -109,10 +109,69 @@ __device__ __forceinline__ uint32_t dpp_of(uint32_t v) { return (uint32_t)__buil
         "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                         \
         : "=&v"(out) : "v"(src), "s"(~keep_max) : "vcc")
 
+// A keep-the-larger mask that is a union of whole 16-lane rows, or of whole 4-lane banks with the
+// same banks in every row, can be applied by the DPP row_mask / bank_mask of the v_max that follows an unconditional v_min -- no
+// v_cndmask and no 64-bit mask in SGPRs (two s_mov per step otherwise): -1 if the mask is not of that shape.
+constexpr int rows_of_mask(uint64_t m)
+{
+    int r = 0;
+    for (int row = 0; row < 4; ++row) {
+        const uint64_t bits = (m >> (16 * row)) & 0xffffull;
+        if (bits == 0xffffull) r |= 1 << row;
+        else if (bits != 0) return -1;
+    }
+    return r;
+}
+constexpr int banks_of_mask(uint64_t m)
+{
+    int b = 0;
+    for (int bank = 0; bank < 4; ++bank) {
+        const uint64_t bits = (m >> (4 * bank)) & 0xfull;
+        if (bits == 0xfull) b |= 1 << bank;
+        else if (bits != 0) return -1;
+    }
+    uint64_t all = 0;
+    for (int row = 0; row < 4; ++row)
+        for (int bank = 0; bank < 4; ++bank)
+            if ((b >> bank) & 1) all |= 0xfull << (16 * row + 4 * bank);
+    return all == m ? b : -1;
+}
+
 template <uint64_t KEEP_MAX, int J>
 __device__ __forceinline__ uint32_t cx_step_m(uint32_t key)
 {
     constexpr uint64_t keep_max = KEEP_MAX;
+#ifndef G2048_BEAM_NO_DPP_MASKS
+    if (J >= 16 && rows_of_mask(KEEP_MAX) > 0) {           // lane swaps: both lanes of a pair hold both keys; the larger on the rows of the mask
+        uint32_t a, b, out;
+        asm("s_nop 1" : "+v"(key));              // (a written-out step may have produced key: wait states before the lane swap reads it)
+        if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); a = r[0]; b = r[1]; }
+        else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); a = r[0]; b = r[1]; }
+        asm("v_min_u32 %0, %1, %2\n\t"
+            "s_nop 0\n\t"                                   // (with the v_min: the wait states between the swap's write and the DPP read)
+            "v_max_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf"
+            : "=&v"(out) : "v"(a), "v"(b), "i"(rows_of_mask(KEEP_MAX)));
+        return out;
+    }
+    if (J == 8 && banks_of_mask(KEEP_MAX) > 0) {
+        uint32_t out;
+        asm("s_nop 1\n\t"
+            "v_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:%2"
+            : "=&v"(out) : "v"(key), "i"(banks_of_mask(KEEP_MAX)));
+        return out;
+    }
+    if (J == 4 && banks_of_mask(KEEP_MAX) > 0) {           // e ^ 3 (quad_perm [3,2,1,0]) into a scratch register, e ^ 7 on the operand = e ^ 4
+        uint32_t out, tmp;
+        asm("s_nop 1\n\t"
+            "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_u32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:%3"
+            : "=&v"(out), "=&v"(tmp) : "v"(key), "i"(banks_of_mask(KEEP_MAX)));
+        return out;
+    }
+#endif
 #ifndef G2048_BEAM_CX_SUBCO          // default: v_max_dpp + v_min_dpp + v_cndmask (A/B switch: the two-instruction form below)
     {
         uint32_t hi, lo;
