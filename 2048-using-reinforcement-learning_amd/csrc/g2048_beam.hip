@@ -761,8 +761,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         }
 #endif
 #ifndef G2048_BEAM_NO_SINGLE
-        // the same for a fast level with 17..64 children: one stream, the 64-key network, hand-over by slots
+        // the same for a fast level with up to 64 children (level 0 included): one stream, the 64-key network, hand-over by slots
+#ifdef G2048_BEAM_SINGLE_FROM_17
         if (PASSES <= 2 && fast && !count_rank && total_valid > 16u && total_valid <= 64u) {
+#else
+        if (PASSES <= 2 && fast && !count_rank && total_valid <= 64u) {
+#endif
             const bool live0 = lane < total_valid;
             const uint4 cv0 = s_cboard[live0 ? lane : 0u];
             const uint32_t cr0 = s_croot[live0 ? lane : 0u];
