@@ -37,12 +37,18 @@ constexpr LaunchPlan launch_plan(int cus, int resident_blocks_per_cu)
 {
     const uint32_t c = cus > 0 ? (uint32_t)cus : (uint32_t)kFallbackCus;
     const uint32_t b = resident_blocks_per_cu > 0 ? (uint32_t)resident_blocks_per_cu : 32u;
-    return LaunchPlan{c * kSimdsPerCu, 4u * c * kSimdsPerCu, c * b / 4u > 0u ? c * b / 4u : 1u};
+#ifndef G2048_HELPER_DIV
+#define G2048_HELPER_DIV 4u
+#endif
+    return LaunchPlan{c * kSimdsPerCu, 4u * c * kSimdsPerCu, c * b / G2048_HELPER_DIV > 0u ? c * b / G2048_HELPER_DIV : 1u};
 }
-static_assert(launch_plan(256, 32).order_row == 1024 && launch_plan(256, 32).order_min == 4096 && launch_plan(256, 32).helper_cap == 2048,
-              "MI355X: the values rounds 1-2 had hard-coded");
+static_assert(launch_plan(256, 32).order_row == 1024 && launch_plan(256, 32).order_min == 4096 &&
+              launch_plan(256, 32).helper_cap == 8192u / G2048_HELPER_DIV, "MI355X: the values rounds 1-2 had hard-coded");
 
-constexpr uint32_t kSpecSlotsPerGame = 8;       // = kSpec below
+#ifndef G2048_SPEC_SLOTS
+#define G2048_SPEC_SLOTS 8
+#endif
+constexpr uint32_t kSpecSlotsPerGame = G2048_SPEC_SLOTS;       // = kSpec below (a power of two)
 constexpr uint32_t default_helpers(uint32_t n_games, uint32_t helper_cap)
 {
     const uint32_t want = n_games / 4u > 1024u ? n_games / 4u : 1024u;
@@ -738,7 +744,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 if (tq.last) s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
             }
 #endif
+#ifdef G2048_BEAM_SPAWN_PREFIX
+            spawn_prefix(c0, rng_draw(k0, k1, gid, j0));
+#else
             spawn(c0, rng_draw(k0, k1, gid, j0));                                // :155 (a no-op on a full board)
+#endif
             draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
             const uint32_t pm0 = cr0 >> 8;
             const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
@@ -773,7 +783,11 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}};
             const uint32_t nm0 = count_empty(c0);
             const unsigned long long b0 = __ballot(live0 && nm0 != 0u);
+#ifdef G2048_BEAM_SPAWN_PREFIX
+            spawn_prefix(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));
+#else
             spawn(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));          // :155 (a no-op on a full board)
+#endif
             draws += (uint32_t)__popcll(b0);
             const uint32_t pm0 = cr0 >> 8;
             const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
