@@ -633,10 +633,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 en_f = on && ((mask >> (vertical ? 1 : 0)) & 1u);
                 en_r = on && ((mask >> (vertical ? 3 : 2)) & 1u);
             } else if (from_pick) {                                              // (beams up to 32 wide: one round)
-                const uint32_t qs = (uint32_t)__shfl((int)pick, (int)(lane >> 1), 64);
-                const uint4 pv = s_cboard[on ? qs : 0u];
+                const uint32_t qs = on ? (uint32_t)__shfl((int)pick, (int)(lane >> 1), 64) : 0u;
+                uint32_t q4 = qs * 4u;
+                asm volatile("" : "+v"(q4));
+                const uint4 pv = s_cboard[qs];
                 P = Board{{pv.x, pv.y, pv.z, pv.w}};
-                ra_f = ra_r = s_croot[on ? qs : 0u];
+                ra_f = ra_r = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_croot) + q4);
             } else if (on) {
                 const uint4 pv = s_board[par];
                 P = Board{{pv.x, pv.y, pv.z, pv.w}};
@@ -644,7 +646,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             }
             Board cf, cr;
             move_axis_sel(P, asel, cf, cr);                                      // :115 / :152 (the agent's DOWN = rot180(true DOWN))
-            const bool vf = en_f && !same(cf, P), vr = en_r && !same(cr, P);
+            const bool vf = en_f & !same(cf, P), vr = en_r & !same(cr, P);       // (no short circuit: one straight block, no exec region)
             const unsigned long long bf = __ballot(vf), br = __ballot(vr);
             const uint32_t before = total_valid + prefix_count(bf) + prefix_count(br);    // valid children generated earlier
             // partner lane (same parent, other axis) through a DPP quad swap
@@ -654,8 +656,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             const uint32_t idx_f = vertical ? before - ((other >> 1) & 1u) : before;
             const uint32_t idx_r = vertical ? before + (mine & 1u) : before + (mine & 1u) + (other & 1u);
             total_valid += (uint32_t)__popcll(bf) + (uint32_t)__popcll(br);
-            if (vf) { s_cboard[idx_f] = make_uint4(cf.w[0], cf.w[1], cf.w[2], cf.w[3]); s_croot[idx_f] = ra_f; }
-            if (vr) { s_cboard[idx_r] = make_uint4(cr.w[0], cr.w[1], cr.w[2], cr.w[3]); s_croot[idx_r] = ra_r; }
+            // (the 4-byte slot address is formed on its own: left to itself the compiler derives it from the 16-byte one with a
+            // 64-bit multiply-add)
+            uint32_t of = idx_f * 4u, orr = idx_r * 4u;
+            asm volatile("" : "+v"(of), "+v"(orr));
+            if (vf) { s_cboard[idx_f] = make_uint4(cf.w[0], cf.w[1], cf.w[2], cf.w[3]); *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_croot) + of) = ra_f; }
+            if (vr) { s_cboard[idx_r] = make_uint4(cr.w[0], cr.w[1], cr.w[2], cr.w[3]); *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_croot) + orr) = ra_r; }
         }
         expanded += total_valid;
         if (total_valid == 0u) {

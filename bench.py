@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-beam", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--no-ppo-rollout", action="store_true", help="skip only the config-4 PPO rollout leg (stock-torch policies)")
     ap.add_argument("--no-evaluation", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the HBM-resident and f64-reward step legs")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -534,7 +535,7 @@ def main():
         del rstream
 
     # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
-    if not args.no_rollout and world == 1:
+    if not args.no_rollout and not args.no_ppo_rollout and world == 1:
         import torch.nn as nn
         from g2048 import RolloutCollector
 
