@@ -750,10 +750,12 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 if (tq.last) s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
             }
 #endif
-#ifdef G2048_BEAM_SPAWN_PREFIX
+#ifdef G2048_BEAM_SPAWN_PREFIX          // A/B switches: the three spawn formulations of g2048_board.h (all exact; profiles/r03_beam_latency.txt)
             spawn_prefix(c0, rng_draw(k0, k1, gid, j0));
+#elif defined(G2048_BEAM_SPAWN_SELECT)
+            spawn(c0, rng_draw(k0, k1, gid, j0));
 #else
-            spawn(c0, rng_draw(k0, k1, gid, j0));                                // :155 (a no-op on a full board)
+            spawn_rowprefix(c0, rng_draw(k0, k1, gid, j0));                      // :155 (a no-op on a full board)
 #endif
             draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
             const uint32_t pm0 = cr0 >> 8;
@@ -791,8 +793,10 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             const unsigned long long b0 = __ballot(live0 && nm0 != 0u);
 #ifdef G2048_BEAM_SPAWN_PREFIX
             spawn_prefix(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));
+#elif defined(G2048_BEAM_SPAWN_SELECT)
+            spawn(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));
 #else
-            spawn(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));          // :155 (a no-op on a full board)
+            spawn_rowprefix(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));    // :155 (a no-op on a full board)
 #endif
             draws += (uint32_t)__popcll(b0);
             const uint32_t pm0 = cr0 >> 8;
@@ -836,8 +840,10 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 draws += (uint32_t)__popcll(bc);
 #ifdef G2048_BEAM_SPAWN_PREFIX      // A/B (round 3: 2.7 % slower at 4096 games although it is 50 issue cycles cheaper per pass)
                 spawn_prefix(c, rng_draw(k0, k1, gid, j));
+#elif defined(G2048_BEAM_SPAWN_SELECT)
+                spawn(c, rng_draw(k0, k1, gid, j));
 #else
-                spawn(c, rng_draw(k0, k1, gid, j));                              // :118 / :155; a no-op on a full board
+                spawn_rowprefix(c, rng_draw(k0, k1, gid, j));                    // :118 / :155; a no-op on a full board
 #endif
                 // :122 / :158-161. What the evaluators need is already known: the empty count (one fewer after a spawn)
                 // and the max code -- a move raises the parent's max by at most one, exactly when some cell now holds

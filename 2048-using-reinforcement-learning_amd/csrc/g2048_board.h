@@ -366,6 +366,25 @@ G2048_HD uint32_t spawn(Board &b, uint32_t h, bool enable = true, uint32_t *zf_o
     return n;
 }
 
+// (1b) row select as in (1), then the k-th empty cell of that row by a byte-wise prefix count of its zero indicators instead
+// of clearing k flags one by one (round 3): (z >> 7) * 0x01010101 has, in byte c, the number of empty cells in columns 0..c;
+// the cell whose count equals k + 1 is the one. A full board needs no special case: its z is 0.
+G2048_HD uint32_t spawn_rowprefix(Board &b, uint32_t h)
+{
+    const uint32_t ones = 0x01010101u;
+    const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
+    const uint32_t c0 = popc(z0), c1 = c0 + popc(z1), c2 = c1 + popc(z2), n = c2 + popc(z3);
+    const uint32_t idx = ((h >> 16) * n) >> 16;
+    const uint32_t row = (idx >= c0 ? 1u : 0u) + (idx >= c1 ? 1u : 0u) + (idx >= c2 ? 1u : 0u);
+    const uint32_t z = row == 0 ? z0 : row == 1 ? z1 : row == 2 ? z2 : z3;
+    const uint32_t k1 = idx + 1u - (row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c1 : c2);      // 1-based rank inside the row
+    const uint32_t hit = zflag(((z >> 7) * ones) ^ (k1 * ones)) & z;
+    const uint32_t add = hit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
+    b.w[0] |= row == 0 ? add : 0u; b.w[1] |= row == 1 ? add : 0u;
+    b.w[2] |= row == 2 ? add : 0u; b.w[3] |= row == 3 ? add : 0u;
+    return n;
+}
+
 // (2) prefix sums: the zero indicators (0/1 per byte) times 0x01010101 give, in byte c of row r, the number of
 // empty cells in columns 0..c of that row; adding the broadcast count of the rows above turns it into the 1-based
 // row-major rank of every empty cell. The chosen cell is the one whose rank equals idx + 1 -- one flag in one of

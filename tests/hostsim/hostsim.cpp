@@ -71,6 +71,8 @@ void hs_spawn(const uint8_t *in, const uint32_t *h, uint8_t *out, size_t n)
         const uint32_t na = spawn(b, h[i], true, za), nb = spawn_prefix(c, h[i], true, zb);
         // the two formulations must agree on everything; a disagreement poisons the output so the test fails
         if (!same(b, c) || na != nb || memcmp(za, zb, sizeof za) != 0) b.w[0] = 0xffffffffu;
+        Board d = ld(in + 16 * i);
+        if (spawn_rowprefix(d, h[i]) != na || !same(d, c)) b.w[0] = 0xffffffffu;        // the third formulation (beam kernel)
         st(out + 16 * i, b);
     }
 }
