@@ -369,7 +369,7 @@ G2048_HD uint32_t spawn(Board &b, uint32_t h, bool enable = true, uint32_t *zf_o
 // (1b) row select as in (1), then the k-th empty cell of that row by a byte-wise prefix count of its zero indicators instead
 // of clearing k flags one by one (round 3): (z >> 7) * 0x01010101 has, in byte c, the number of empty cells in columns 0..c;
 // the cell whose count equals k + 1 is the one. A full board needs no special case: its z is 0.
-G2048_HD uint32_t spawn_rowprefix(Board &b, uint32_t h)
+G2048_HD uint32_t spawn_rowprefix(Board &b, uint32_t h, bool enable = true, uint32_t *zf_out = nullptr)
 {
     const uint32_t ones = 0x01010101u;
     const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
@@ -378,10 +378,14 @@ G2048_HD uint32_t spawn_rowprefix(Board &b, uint32_t h)
     const uint32_t row = (idx >= c0 ? 1u : 0u) + (idx >= c1 ? 1u : 0u) + (idx >= c2 ? 1u : 0u);
     const uint32_t z = row == 0 ? z0 : row == 1 ? z1 : row == 2 ? z2 : z3;
     const uint32_t k1 = idx + 1u - (row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c1 : c2);      // 1-based rank inside the row
-    const uint32_t hit = zflag(((z >> 7) * ones) ^ (k1 * ones)) & z;
+    const uint32_t hit = zflag(((z >> 7) * ones) ^ (enable ? k1 * ones : 0x7f7f7f7fu)) & z;       // 0x7f: never a rank
     const uint32_t add = hit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
     b.w[0] |= row == 0 ? add : 0u; b.w[1] |= row == 1 ? add : 0u;
     b.w[2] |= row == 2 ? add : 0u; b.w[3] |= row == 3 ? add : 0u;
+    if (zf_out) {               // zero flags of the board AFTER the spawn
+        zf_out[0] = z0 ^ (row == 0 ? hit : 0u); zf_out[1] = z1 ^ (row == 1 ? hit : 0u);
+        zf_out[2] = z2 ^ (row == 2 ? hit : 0u); zf_out[3] = z3 ^ (row == 3 ? hit : 0u);
+    }
     return n;
 }
 
@@ -543,6 +547,8 @@ G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain,
 // The same value with the first three terms folded: gain/4, -2.0 for an invalid move and (after - before) * 0.5 are
 // all exact multiples of 0.25 of small magnitude, so the reference's three roundings are no-ops and the partial
 // sum equals (gain - 8*[invalid] + 2*(after - before)) * 0.25 exactly -- one conversion and one multiply.
+// (Round 3 tried the four products (double)c * 0.1 from an 8-entry LDS table: the table fill and the address arithmetic cost
+// more than the conversions and multiplications they replace: 386 against 374 static instructions. Not kept.)
 G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
                                   uint32_t empty_before, uint32_t empty_after)
 {
