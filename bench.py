@@ -422,7 +422,19 @@ def main():
                                            "board_steps_per_s": nb / us * 1e6,
                                            "note": "16,777,216 boards per launch: 738 MB of streams, beyond the 256 MiB "
                                                    "Infinity Cache, so reads come from and writes go to HBM3E"}
-        del bb, ba, bo, bs, br, bf, gb
+        # rounds 1-2 timed 10 launches per replay (1.6 ms): kept beside the 40-launch reading for like-for-like comparison
+        def big_steps10():
+            for t in range(10):
+                ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
+        g10, a10, b10 = (None, None, None) if args.no_graph else graph_of(big_steps10, dev)
+        ms10 = [timed_replay(g10, a10, b10, big_steps10, reps=1) for _ in range(4)]
+        result["roofline_hbm_resident"]["frac_10_launch_replays"] = nb * STEP_BYTES_F32 / (min(ms10) * 1e3 / 10) / 1e3 / HBM_PEAK_GBS
+        result["roofline_hbm_resident"]["frac_10_launch_replays_mean_of_4"] = (nb * STEP_BYTES_F32 / (sum(ms10) / len(ms10) * 1e3 / 10) / 1e3
+                                                                              / HBM_PEAK_GBS)
+        result["roofline_hbm_resident"]["timing"] = ("event pair around one hipGraph replay of 40 launches queued behind another one "
+                                                     "(6 ms: steady-state clocks), best and mean of four; rounds 1-2 replayed 10 launches "
+                                                     "(frac_10_launch_replays: 0.586 in round 2)")
+        del bb, ba, bo, bs, br, bf, gb, g10
         torch.cuda.empty_cache()
 
     # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
