@@ -88,6 +88,20 @@ class VecGame2048:
         info = _StepInfo(self)
         return self.boards, self.reward, done, info
 
+    def random_playout(self, steps, want_rewards=False, want_flags=False, want_episodes=False):
+        """`steps` random-playout steps of every board in ONE launch (g2048_step_many: the boards stay in registers between
+        the steps): exactly `steps` calls of `step()` without actions, minus the per-step round trips. Returns (boards, last
+        flags, reward stream (steps, n) or None, flags stream (steps, n) or None, episodes finished per board or None);
+        `self.reward` is not updated (ask for the stream)."""
+        steps = int(steps)
+        out, flags, rewards, fstream, episodes = ops.step_many(
+            self.boards, self.scores, self.seed, self.t, steps, self.id_base, out=self._spare, flags=self.flags,
+            reward_f64=self.reward_f64, auto_reset=self.auto_reset, want_rewards=want_rewards, want_flags=want_flags,
+            want_episodes=want_episodes)
+        self.boards, self._spare = self._spare, self.boards
+        self.t += steps
+        return self.boards, flags, rewards, fstream, episodes
+
     def valid_moves(self, agent_semantics=False):
         """uint8 (n,) 4-bit masks, bit a = action a valid."""
         return ops.valid_moves(self.boards, agent_semantics)

@@ -522,3 +522,22 @@ def test_step_many_argument_checks(ops):
     with pytest.raises(ValueError):
         ops.step_many(b, s, 1, 0, 0)
     assert L.lib().g2048_step_many(None, None, None, None, None, None, None, 1, 0, 4, 0, 0, 4, None) == 0       # n = 0: a no-op
+
+
+def test_vec_env_random_playout_equals_steps(ops):
+    """VecGame2048.random_playout(T) == T calls of step() without actions (same boards, scores, flags, rewards, step counter)."""
+    from g2048 import VecGame2048
+    n, T = 70001, 37
+    e1 = VecGame2048(n, device=DEV, seed=11, id_base=9 << 32, auto_reset=True)
+    e2 = VecGame2048(n, device=DEV, seed=11, id_base=9 << 32, auto_reset=True)
+    rs = []
+    for t in range(T):
+        b1, r1, d1, _ = e1.step()
+        rs.append(r1.clone())
+    b2, fl, rew, _, eps = e2.random_playout(T, want_rewards=True, want_episodes=True)
+    assert bool((b1 == b2).all()) and bool((e1.scores == e2.scores).all()) and bool((e1.flags == fl).all()) and e1.t == e2.t == T
+    assert np.array_equal(host(torch.stack(rs)), host(rew), equal_nan=True) and int(eps.sum()) > 0
+    b1, r1, d1, _ = e1.step()                       # and the two envs stay in step afterwards
+    b2, r2, d2, _ = e2.step()
+    assert bool((b1 == b2).all()) and np.array_equal(host(r1), host(r2), equal_nan=True)
+
