@@ -51,7 +51,7 @@ static_assert(launch_plan(256, 32).order_row == 1024 && launch_plan(256, 32).ord
 constexpr uint32_t kSpecSlotsPerGame = G2048_SPEC_SLOTS;       // = kSpec below (a power of two)
 constexpr uint32_t default_helpers(uint32_t n_games, uint32_t helper_cap)
 {
-    const uint32_t want = n_games / 4u > 1024u ? n_games / 4u : 1024u;
+    const uint32_t want = n_games / 2u > 1024u ? n_games / 2u : 1024u;      // round 3: half the games (a quarter before)
     const uint32_t most = kSpecSlotsPerGame * n_games < want ? kSpecSlotsPerGame * n_games : want;
     return most < helper_cap ? most : helper_cap;
 }
@@ -1391,10 +1391,10 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         else G2048_LAUNCH_PLAY(8);
 #undef G2048_LAUNCH_PLAY
     } else {
-        // Helpers: four per game for a small batch, a quarter of the games for a large one, never more than a quarter of the
+        // Helpers: eight per game for a small batch, half the games for a large one, never more than a quarter of the
         // wavefronts the device holds at once (launch_plan: CUs x resident blocks per CU / 4 -- 2048 on a whole MI355X), so
         // owners always find room whatever the dispatch order. A game registers for them once it is stuck (16 more invalid
-        // than valid moves lately) or once an eighth of the games (at least 256) is left; an owner polls at most 60 us for a
+        // than valid moves lately) or once an eighth of the games (at least 256) is left; an owner polls at most 150 us for a
         // posted result. Measured flat around these values (profiles/r02_eval_helpers.txt); g2048_play_games_tuned overrides
         // them for measurements and tests (every field clamped).
         const uint32_t n = (uint32_t)n_games;
@@ -1410,7 +1410,7 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         uint32_t helpers = default_helpers(n, plan.helper_cap);
         uint32_t games_left = std::max<uint32_t>(n / 8u, 256u);
         int stuck_thr = 16;
-        uint32_t wait_us = 60;
+        uint32_t wait_us = 150;             // round 3 (60 before; profiles/r03_eval_helpers.txt)
         if (tuning) {
             helpers = std::min<uint32_t>(std::min<uint32_t>(tuning[0], (uint32_t)kSpec * n), plan.helper_cap);
             games_left = tuning[1];

@@ -226,8 +226,8 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
  * the same for every setting; only the time changes). tuning4 = { helper wavefronts (clamped to 8 per game and to the
  * device's cap, g2048_launch_plan), games left at which every remaining game registers for helpers (>= n_games: at once),
  * "stuck" threshold = invalid minus valid moves at which a game registers early (clamped to 1 .. 2^20), microseconds an
- * owner polls for a posted result (clamped to 1000) }. The defaults g2048_play_games uses: { min(8 n, max(n / 4, 1024), cap),
- * max(n / 8, 256), 16, 60 }. */
+ * owner polls for a posted result (clamped to 1000) }. The defaults g2048_play_games uses: { min(8 n, max(n / 2, 1024), cap),
+ * max(n / 8, 256), 16, 150 }. */
 int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                            int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
                            uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,

@@ -45,8 +45,9 @@ def test_launch_plan_arithmetic(built):
     as the library derives it from a compute-unit count: MI355X (256 CUs), a quarter partition (64), one XCD (32)."""
     from g2048 import ops
     full = ops.launch_plan(256, 32, 4096)
-    assert full == dict(order_row=1024, order_min_games=4096, helper_cap=2048, default_helpers=1024)      # rounds 1-2's constants
+    assert full == dict(order_row=1024, order_min_games=4096, helper_cap=2048, default_helpers=2048)      # rounds 1-2's constants (helpers: half the games since round 3)
     assert ops.launch_plan(256, 32, 16384)["default_helpers"] == 2048 and ops.launch_plan(256, 32, 100)["default_helpers"] == 800
+    assert ops.launch_plan(256, 32, 2048)["default_helpers"] == 1024 and ops.launch_plan(256, 32, 3000)["default_helpers"] == 1500
     q = ops.launch_plan(64, 32, 4096)
     assert q == dict(order_row=256, order_min_games=1024, helper_cap=512, default_helpers=512)
     x = ops.launch_plan(32, 32, 4096)
