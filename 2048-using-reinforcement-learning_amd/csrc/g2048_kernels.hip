@@ -151,9 +151,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
 // and the direction table stay in registers / LDS for all T steps, the per-step keys of the three RNG domains are derived
 // on the scalar unit from (seed, domain, step index) -- the same keys the host derives for g2048_step -- and only what
 // the caller asks for per step (reward / flags streams) is written. Step t is bit-for-bit g2048_step(step_index0 + t,
-// G2048_STEP_RANDOM_ACTIONS [| G2048_STEP_AUTO_RESET]).
-template <bool REWARD_F64, bool AUTO_RESET, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in, uint4 *boards_out, uint32_t *__restrict__ score,
+// G2048_STEP_RANDOM_ACTIONS [| G2048_STEP_AUTO_RESET]) -- or, with RANDOM false, g2048_step with the explicit action
+// actions[t * n + i] (a recorded move sequence, an open-loop plan): the next step's action byte is requested before this
+// step is computed, so the load never sits on the dependent chain.
+template <bool REWARD_F64, bool AUTO_RESET, int BLOCK, bool RANDOM = true>
+__global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in, const uint8_t *__restrict__ actions,
+                                                          uint4 *boards_out, uint32_t *__restrict__ score,
                                                           void *__restrict__ reward_stream, uint8_t *__restrict__ flags_stream,
                                                           uint8_t *__restrict__ flags_last, uint32_t *__restrict__ episodes_out,
                                                           uint64_t seed, uint64_t step_index0, uint32_t steps, uint64_t id_base,
@@ -171,10 +174,20 @@ __global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in
     float *rw32 = static_cast<float *>(reward_stream) + block0;
     double *rw64 = static_cast<double *>(reward_stream) + block0;
     uint8_t *fl = flags_stream + block0;
+    const uint8_t *act = actions + block0;
+    uint32_t next_action = RANDOM ? 0u : (uint32_t)act[j];
     for (uint32_t t = 0; t < steps; ++t) {
         const uint64_t index = step_index0 + t;                          // uniform: scalar unit
-        const Keys ks = rng_keys(seed, DOM_STEP, index), ka = rng_keys(seed, DOM_SYNTH_ACTION, index);
-        const uint32_t action = rng_draw(ka.k0, ka.k1, id, 0u) >> 30;       // what g2048_synth_actions would write
+        const Keys ks = rng_keys(seed, DOM_STEP, index);
+        uint32_t action;
+        if (RANDOM) {
+            const Keys ka = rng_keys(seed, DOM_SYNTH_ACTION, index);
+            action = rng_draw(ka.k0, ka.k1, id, 0u) >> 30;                  // what g2048_synth_actions would write
+        } else {
+            action = next_action & 3u;                                   // (the low two bits count, as in g2048_step)
+            act += n;
+            if (t + 1u < steps) next_action = (uint32_t)act[j];
+        }
         const StepOut o = step_board_sel(cur, dir_sel(s_dir, action), rng_draw(ks.k0, ks.k1, id, 0u));
         cur = o.board;
         sc += o.gain;
@@ -582,28 +595,34 @@ int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_o
                      keyblock);
 }
 
-int g2048_step_many(const void *boards_in, void *boards_out, uint32_t *score_inout, void *reward_stream_out_or_null,
-                    uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out, uint32_t *episodes_out_or_null, uint64_t seed,
-                    uint64_t step_index0, uint32_t steps, uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
+int g2048_step_many(const void *boards_in, const uint8_t *actions_stream_or_null, void *boards_out, uint32_t *score_inout,
+                    void *reward_stream_out_or_null, uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out,
+                    uint32_t *episodes_out_or_null, uint64_t seed, uint64_t step_index0, uint32_t steps,
+                    uint64_t board_id_base, size_t n, uint32_t opts, void *stream)
 {
     if (n == 0) return G2048_OK;
     if (!boards_in || !boards_out || !score_inout || !flags_last_out) return fail(G2048_ERR_ARG, "g2048_step_many: null pointer");
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step_many: board arrays must be 16-byte aligned");
     const bool f64 = (opts & G2048_STEP_REWARD_F64) != 0u, ar = (opts & G2048_STEP_AUTO_RESET) != 0u;
+    const bool random_actions = (opts & G2048_STEP_RANDOM_ACTIONS) != 0u;
     if (!aligned4(score_inout) || (episodes_out_or_null && !aligned4(episodes_out_or_null)) ||
         (reward_stream_out_or_null && (reinterpret_cast<uintptr_t>(reward_stream_out_or_null) & (f64 ? 7u : 3u))))
         return fail(G2048_ERR_ARG, "g2048_step_many: score / reward / episode arrays misaligned");
-    if (!(opts & G2048_STEP_RANDOM_ACTIONS)) return fail(G2048_ERR_ARG, "g2048_step_many: the in-kernel policy is G2048_STEP_RANDOM_ACTIONS (set it)");
+    if (!random_actions && !actions_stream_or_null)
+        return fail(G2048_ERR_ARG, "g2048_step_many: no policy: pass an actions stream or set G2048_STEP_RANDOM_ACTIONS");
     if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS)) return fail(G2048_ERR_ARG, "g2048_step_many: unknown opts 0x%x", opts);
     if (steps == 0) return fail(G2048_ERR_ARG, "g2048_step_many: steps must be at least 1");
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define G2048_LAUNCH_MANY(F, A) hipLaunchKernelGGL((step_many_kernel<F, A, kBlock>), dim3(blocks_for(n)), dim3(kBlock), 0, s, \
-                           static_cast<const uint4 *>(boards_in), static_cast<uint4 *>(boards_out), score_inout, reward_stream_out_or_null, \
-                           flags_stream_out_or_null, flags_last_out, episodes_out_or_null, seed, step_index0, steps, board_id_base, n)
-    if (f64 && ar) G2048_LAUNCH_MANY(true, true);
-    else if (f64) G2048_LAUNCH_MANY(true, false);
-    else if (ar) G2048_LAUNCH_MANY(false, true);
-    else G2048_LAUNCH_MANY(false, false);
+#define G2048_LAUNCH_MANY(F, A, R) hipLaunchKernelGGL((step_many_kernel<F, A, kBlock, R>), dim3(blocks_for(n)), dim3(kBlock), 0, s, \
+                           static_cast<const uint4 *>(boards_in), actions_stream_or_null, static_cast<uint4 *>(boards_out), score_inout, \
+                           reward_stream_out_or_null, flags_stream_out_or_null, flags_last_out, episodes_out_or_null, seed, step_index0, \
+                           steps, board_id_base, n)
+#define G2048_LAUNCH_MANY_R(F, A) do { if (random_actions) G2048_LAUNCH_MANY(F, A, true); else G2048_LAUNCH_MANY(F, A, false); } while (0)
+    if (f64 && ar) G2048_LAUNCH_MANY_R(true, true);
+    else if (f64) G2048_LAUNCH_MANY_R(true, false);
+    else if (ar) G2048_LAUNCH_MANY_R(false, true);
+    else G2048_LAUNCH_MANY_R(false, false);
+#undef G2048_LAUNCH_MANY_R
 #undef G2048_LAUNCH_MANY
     return check_launch("g2048_step_many");
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
     "g2048_abi_version": (_int, []),
     "g2048_device_count": (_int, []),
     "g2048_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _u32, _vp]),
-    "g2048_step_many": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u32, _u64, _sz, _u32, _vp]),
+    "g2048_step_many": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u32, _u64, _sz, _u32, _vp]),
     "g2048_reset": (_int, [_vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_valid_moves": (_int, [_vp, _vp, _sz, _u32, _vp]),
     "g2048_eval": (_int, [_vp, _int, _vp, _vp, _sz, _vp]),

@@ -104,15 +104,21 @@ class PreparedStep:
 
 def step_many(boards, scores, seed, step_index0, steps, id_base=0, out=None, flags=None, reward_stream=None,
               flags_stream=None, episodes=None, reward_f64=False, auto_reset=False, want_rewards=False, want_flags=False,
-              want_episodes=False):
-    """`steps` consecutive random-playout steps of every board in ONE launch (g2048_step_many): step t equals
-    `step(boards, None, scores, seed, step_index0 + t, id_base, auto_reset=...)` bit for bit, but the boards stay in registers
-    between the steps. scores is updated in place; `out` may be `boards`. Returns (boards_out, flags_last, reward_stream or
-    None, flags_stream or None, episodes or None); the streams are (steps, n) tensors, allocated when want_* is set."""
+              want_episodes=False, actions=None):
+    """`steps` consecutive steps of every board in ONE launch (g2048_step_many): step t equals
+    `step(boards, actions[t] or None, scores, seed, step_index0 + t, id_base, auto_reset=...)` bit for bit, but the boards stay
+    in registers between the steps. actions=None: random playout (uniform actions drawn in the kernel); else a uint8 (steps, n)
+    tensor of explicit actions. scores is updated in place; `out` may be `boards`. Returns (boards_out, flags_last,
+    reward_stream or None, flags_stream or None, episodes or None); the streams are (steps, n) tensors, allocated when want_*
+    is set."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     n, steps = boards.shape[0], int(steps)
     if steps < 1:
         raise ValueError("g2048: steps must be at least 1")
+    if actions is not None:
+        L.require_device_tensor(actions, torch.uint8, None, "actions")
+        if tuple(actions.shape) != (steps, n):
+            raise ValueError("g2048: actions must have shape (steps, n)")
     _require_scores(scores)
     if scores.shape[0] != n:
         raise ValueError("g2048: scores length must equal the number of boards")
@@ -137,8 +143,10 @@ def step_many(boards, scores, seed, step_index0, steps, id_base=0, out=None, fla
                 raise ValueError("g2048: %s must have shape (steps, n)" % name)
     if episodes is not None:
         L.require_device_tensor(episodes, torch.int32, None, "episodes")
-    opts = L.STEP_RANDOM_ACTIONS | (L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0)
-    L.call(dev, L.lib().g2048_step_many, boards.data_ptr(), out.data_ptr(), scores.data_ptr(),
+    opts = ((L.STEP_RANDOM_ACTIONS if actions is None else 0) | (L.STEP_REWARD_F64 if reward_f64 else 0) |
+            (L.STEP_AUTO_RESET if auto_reset else 0))
+    L.call(dev, L.lib().g2048_step_many, boards.data_ptr(), None if actions is None else actions.data_ptr(), out.data_ptr(),
+           scores.data_ptr(),
            None if reward_stream is None else reward_stream.data_ptr(), None if flags_stream is None else flags_stream.data_ptr(),
            flags.data_ptr(), None if episodes is None else episodes.data_ptr(), L.u64(seed), L.u64(step_index0), steps,
            L.u64(id_base), n, opts, L.stream_ptr(dev))

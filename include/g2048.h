@@ -112,18 +112,21 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out,
                uint64_t seed, uint64_t step_index, uint64_t board_id_base, size_t n,
                uint32_t opts, void *stream);
 
-/* `steps` consecutive Game2048Env.step calls (environment/game_2048.py:170-210) of every board in ONE launch -- random
- * playouts, SURVEY 8d C2 "rollout" variant: the board and its score stay in registers between the steps instead of making a
- * 46-byte round trip through memory per step. Step t (0 <= t < steps) is bit-for-bit g2048_step(step_index = step_index0 + t)
- * with the same opts: G2048_STEP_RANDOM_ACTIONS is required (the actions are the in-kernel uniform draws; there is no other
- * in-kernel policy), G2048_STEP_AUTO_RESET and G2048_STEP_REWARD_F64 are optional. boards_out may alias boards_in.
+/* `steps` consecutive Game2048Env.step calls (environment/game_2048.py:170-210) of every board in ONE launch: the board and
+ * its score stay in registers between the steps instead of making a 46-byte round trip through memory per step. Step t
+ * (0 <= t < steps) is bit-for-bit g2048_step(step_index = step_index0 + t) with the same opts. The actions are either the
+ * in-kernel uniform draws (G2048_STEP_RANDOM_ACTIONS: random playouts, SURVEY 8d C2 "rollout" variant; actions_stream_or_null
+ * is ignored and may be NULL) or explicit, step-major: actions_stream_or_null[t * n + i] (low two bits, as in g2048_step) --
+ * a recorded move sequence such as the reference's checkpoints/ move-set files (BeamSearchAgent_best_moveset_tile_N.txt), or an open-loop plan; a policy that needs the
+ * state of step t to choose action t uses g2048_step / g2048_rollout_step. G2048_STEP_AUTO_RESET and G2048_STEP_REWARD_F64
+ * are optional. boards_out may alias boards_in.
  * Outputs: the boards and scores after the last step, flags_last_out[i] = the flags byte of the last step; optional per-step
  * streams, step-major: reward_stream_out_or_null[t * n + i] (float, or double with G2048_STEP_REWARD_F64) and
  * flags_stream_out_or_null[t * n + i]; episodes_out_or_null[i] = episodes board i finished (auto-resets taken). */
-int g2048_step_many(const void *boards_in, void *boards_out, uint32_t *score_inout, void *reward_stream_out_or_null,
-                    uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out, uint32_t *episodes_out_or_null,
-                    uint64_t seed, uint64_t step_index0, uint32_t steps, uint64_t board_id_base, size_t n,
-                    uint32_t opts, void *stream);
+int g2048_step_many(const void *boards_in, const uint8_t *actions_stream_or_null, void *boards_out, uint32_t *score_inout,
+                    void *reward_stream_out_or_null, uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out,
+                    uint32_t *episodes_out_or_null, uint64_t seed, uint64_t step_index0, uint32_t steps,
+                    uint64_t board_id_base, size_t n, uint32_t opts, void *stream);
 
 /* Game2048Env.reset for n boards (environment/game_2048.py:29-48). score_out may be NULL. */
 int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch,

@@ -515,13 +515,39 @@ def test_step_many_argument_checks(ops):
     b, s = ops.reset(64, 1, 0, 0, device=DEV)
     from g2048 import _lib as L
     fl = torch.empty(64, dtype=torch.uint8, device=DEV)
-    rc = L.lib().g2048_step_many(b.data_ptr(), b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 4, 0, 64, 0, None)
-    assert rc == -1 and b"RANDOM_ACTIONS" in L.lib().g2048_last_error()
-    rc = L.lib().g2048_step_many(b.data_ptr(), b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 0, 0, 64, 4, None)
+    rc = L.lib().g2048_step_many(b.data_ptr(), None, b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 4, 0, 64, 0, None)
+    assert rc == -1 and b"RANDOM_ACTIONS" in L.lib().g2048_last_error()          # neither an actions stream nor the in-kernel policy
+    rc = L.lib().g2048_step_many(b.data_ptr(), None, b.data_ptr(), s.data_ptr(), None, None, fl.data_ptr(), None, 1, 0, 0, 0, 64, 4, None)
     assert rc == -1
     with pytest.raises(ValueError):
         ops.step_many(b, s, 1, 0, 0)
-    assert L.lib().g2048_step_many(None, None, None, None, None, None, None, 1, 0, 4, 0, 0, 4, None) == 0       # n = 0: a no-op
+    with pytest.raises(ValueError):
+        ops.step_many(b, s, 1, 0, 3, actions=torch.zeros((2, 64), dtype=torch.uint8, device=DEV))
+    assert L.lib().g2048_step_many(None, None, None, None, None, None, None, None, 1, 0, 4, 0, 0, 4, None) == 0       # n = 0: a no-op
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_many_with_explicit_actions(ops, oracle, auto_reset):
+    """g2048_step_many fed a step-major stream of explicit actions == one g2048_step launch per step with those actions, and
+    == the oracle (boards, scores, f64 rewards, flags) -- e.g. a recorded move sequence replayed on many boards at once."""
+    n, T, seed, base = 50021, 40, 77, 1 << 36
+    b0, s0 = ops.reset(n, seed, 0, base, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    acts = torch.randint(0, 256, (T, n), generator=g, dtype=torch.uint8).to(DEV)        # high bits set: only the low two count
+    b, sc = b0.clone(), s0.clone()
+    hb, hs = host(b0), host(s0).astype(np.uint32)
+    rws, fls = [], []
+    for t in range(T):
+        b, rw, fl = ops.step(b, acts[t].contiguous(), sc, seed, 5 + t, base, reward_f64=True, auto_reset=auto_reset)
+        rws.append(rw); fls.append(fl)
+        if t < 3:
+            hb, hs, hr, hf = oracle.step_batch(hb, host(acts[t]) & 3, hs, seed=seed, step_index=5 + t, id_base=base, opts=int(auto_reset))
+            assert np.array_equal(host(b), hb) and np.array_equal(host(rw), hr, equal_nan=True) and np.array_equal(host(fl), hf)
+    sm = s0.clone()
+    out, flast, rstream, fstream, _ = ops.step_many(b0.clone(), sm, seed, 5, T, base, reward_f64=True, auto_reset=auto_reset,
+                                                    want_rewards=True, want_flags=True, actions=acts)
+    assert bool((out == b).all()) and bool((sm == sc).all()) and bool((flast == fls[-1]).all())
+    assert np.array_equal(host(rstream), host(torch.stack(rws)), equal_nan=True) and bool((fstream == torch.stack(fls)).all())
 
 
 def test_vec_env_random_playout_equals_steps(ops):
