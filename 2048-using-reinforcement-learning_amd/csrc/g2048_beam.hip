@@ -392,155 +392,9 @@ struct BeamShared {
 
 struct Decision { uint32_t action; float prob; uint32_t expanded; };
 
-// ---------------------------------------------------------------- lane-resident search (round 3; beams up to 32 wide)
-// With four wavefronts per SIMD (4096 concurrent games) a search is bound by the latency of ITS OWN dependent instruction
-// chain, not by instruction issue: one wavefront alone runs at 35 % of a SIMD's issue rate, two at 55 %, four at 76 %
-// (profiles/r03_beam_latency.txt). This formulation is built for that chain:
-//   * lane = axis * 32 + p owns parent p's two children of one axis (lower half: LEFT / RIGHT, upper half: UP / DOWN) from the
-//     move to the key -- move, validity, spawn, score run as two independent instruction streams per lane, and nothing is
-//     compacted through LDS in between (round 2: children to LDS in generation order, barrier, read back 64 per pass);
-//   * generation order (parent rank, action) -- the reference's RNG consumption order and the tie order of its stable sort --
-//     comes from four half-wave ballots; a child's draw is its generation index minus the "changed but full" children before it
-//     (only the reference's rot180-DOWN quirk produces those);
-//   * the fast levels rank by top32_of_pair: four quarter sets sorted at once, 26 step latencies instead of 37;
-//   * the spawned children go to LDS at their generation index, the sorted keys ARE the next beam: the low nine bits of the
-//     key in lane r name the LDS slot of the rank-r child, lane 32 + r takes it through v_permlane32_swap, and the next level
-//     reads its parent from there -- no beam array, no barrier: one LDS read per level sits on the dependent chain (round 2:
-//     four round trips and three barriers);
-//   * levels 1..3 (f64 scores of _evaluate_state) rank by counting over the scores in LDS and hand the slots over through a
-//     small rank -> slot table.
-// LDS ordering needs no barrier: one wavefront's LDS operations execute in order, and every level reads its parents (one
-// instruction, all lanes) before it writes its children.
-template <int PASSES>
-__device__ __forceinline__ Decision beam_decide_lanes(BeamShared<PASSES> &sh, const Board &root, int mask_in, int width, int depth,
-                                                      uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1, uint64_t gid,
-                                                      bool fixed_down)
-{
-    uint4 *const s_child = sh.cboard;                  // spawned children of the current level, by generation index (<= 4 * 32)
-    uint32_t *const s_info = sh.croot;                 //   root action | max code << 8
-    double *const s_score = sh.score;                  // f64 levels: scores by generation index
-    uint32_t *const s_order = sh.root;                 // f64 levels: rank -> generation index
-    const uint32_t lane = threadIdx.x, p = lane & 31u;
-    const bool upper = lane >= 32u;                     // vertical axis: fwd = UP (1), rev = DOWN (3); lower: LEFT (0), RIGHT (2)
-    const uint32_t u = upper ? 1u : 0u;
-
-    const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);   // :82-93
-    const uint32_t nvalid = popc(mask);
-    if (nvalid <= 1u) return Decision{nvalid ? (uint32_t)__builtin_ctz(mask) : 0u, nvalid ? 1.0f : 0.5f, 0u};
-    const uint32_t root_max = max_code(root);                                                             // :96-106
-    const uint32_t phase = phase_of(root_max, early_thr, mid_thr);
-    const uint32_t root_empty = count_empty(root);
-    int actual_depth;
-    if (root_empty <= 4u) actual_depth = min(depth + 5, 25);
-    else if (root_empty >= 10u) actual_depth = min(depth - 5, 10);
-    else actual_depth = depth;
-
-    AxisSel asel = axis_sel(upper, fixed_down);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(asel.in[k]), "+v"(asel.fwd[k]), "+v"(asel.rev[k]));   // loop-invariant registers
-
-    int nb = 0;                      // beam size
-    uint32_t q = 0u;                 // LDS slot of this lane's parent (p < nb)
-    uint32_t best = 0u;              // LDS slot of the rank-0 child of the last ranked level (wave-uniform)
-    uint32_t draws = 0u, expanded = 0u;
-    for (int level = 0; level == 0 || level < actual_depth; ++level) {
-        const bool fast = level == 0 || level > 3;                               // :122, :139
-        const int n_parents = level == 0 ? 1 : nb;
-        const bool on = (int)p < n_parents;
-        Board P = root;
-        uint32_t ra_f = u | (root_max << 8), ra_r = (2u + u) | (root_max << 8);
-        bool en_f = on, en_r = on;
-        if (level == 0) {
-            en_f = on && ((mask >> u) & 1u);
-            en_r = on && ((mask >> (2u + u)) & 1u);
-        } else {
-            const uint4 pv = s_child[on ? q : 0u];
-            P = Board{{pv.x, pv.y, pv.z, pv.w}};
-            ra_f = ra_r = s_info[on ? q : 0u];
-        }
-        Board cf, cr;
-        move_axis_sel(P, asel, cf, cr);                                          // :115 / :152 (DOWN = rot180(true DOWN))
-        const bool vf = en_f && !same(cf, P), vr = en_r && !same(cr, P);
-        const uint32_t ef = count_empty(cf), er = count_empty(cr);
-        const unsigned long long bf = __ballot(vf), br = __ballot(vr);
-        // a child with an empty cell consumes the next draw, in generation order (:262-269); only the quirk's DOWN can be a
-        // "changed" board without one
-        const unsigned long long bx = __ballot(vr && er == 0u);
-        const uint32_t bf_lo = (uint32_t)bf, bf_hi = (uint32_t)(bf >> 32), br_lo = (uint32_t)br, br_hi = (uint32_t)(br >> 32);
-        const uint32_t total_valid = (uint32_t)__popcll(bf) + (uint32_t)__popcll(br);
-        if (total_valid == 0u) {
-            if (level == 0) {                                                   // :126-128 random valid action, prob 0.5
-                uint32_t idx = ((rng_draw(k0, k1, gid, draws) >> 16) * nvalid) >> 16;
-                uint32_t m = mask;
-                while (idx--) m &= m - 1u;
-                return Decision{(uint32_t)__builtin_ctz(m), 0.5f, 0u};
-            }
-            break;                                                              // :170-171 keep the previous beam
-        }
-        // valid children of the parents before p: bit p of the four half-ballots, counted below p (mbcnt_lo serves the lower
-        // lanes and returns the full count for the upper ones, mbcnt_hi serves the upper lanes: start those at -total)
-        uint32_t before = upper ? 0u - total_valid : 0u;
-        before = __builtin_amdgcn_mbcnt_lo(bf_lo, __builtin_amdgcn_mbcnt_lo(bf_hi, before));
-        before = __builtin_amdgcn_mbcnt_lo(br_lo, __builtin_amdgcn_mbcnt_lo(br_hi, before));
-        uint32_t before_hi = __builtin_amdgcn_mbcnt_hi(bf_lo, __builtin_amdgcn_mbcnt_hi(bf_hi, 0u));
-        before_hi = __builtin_amdgcn_mbcnt_hi(br_lo, __builtin_amdgcn_mbcnt_hi(br_hi, before_hi));
-        before += before_hi;
-        // the other axis of the same parent sits 32 lanes away; order inside a parent: LEFT UP RIGHT DOWN
-        const uint32_t mine = (vf ? 1u : 0u) | (vr ? 2u : 0u);
-        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-        const uint32_t other = upper ? sw[0] : sw[1];                             // [0] = {lower, lower}, [1] = {upper, upper}
-        const uint32_t g_f = before + (other & u);                                // UP comes after LEFT
-        const uint32_t g_r = before + (mine & 1u) + (other & 1u) + ((other >> 1) & u);   // RIGHT after LEFT UP; DOWN after all three
-        uint32_t xb = 0u;
-        if (bx) {                                                                // (rare) DOWNs without a draw among the parents before p
-            const uint32_t x = (uint32_t)(bx >> 32);
-            xb = upper ? __builtin_amdgcn_mbcnt_hi(x, 0u) : __builtin_amdgcn_mbcnt_lo(x, 0u);
-        }
-        spawn(cf, rng_draw(k0, k1, gid, draws + g_f - xb));                      // :118 / :155; a no-op on a full board
-        spawn(cr, rng_draw(k0, k1, gid, draws + g_r - xb));
-        draws += total_valid - (uint32_t)__popcll(bx);
-        expanded += total_valid;
-        // :122 / :158-161 with what is already known: the empty count (one fewer after a spawn) and the max code -- a move
-        // raises the parent's max by at most one, exactly when some cell now holds parent max + 1
-        const uint32_t pmax = ra_f >> 8;
-        const uint32_t cmf = pmax + (has_code(cf, pmax + 1u) ? 1u : 0u), cmr = pmax + (has_code(cr, pmax + 1u) ? 1u : 0u);
-        const uint32_t nf = ef - (ef ? 1u : 0u), nr = er - (er ? 1u : 0u);
-        if (vf) { s_child[g_f] = make_uint4(cf.w[0], cf.w[1], cf.w[2], cf.w[3]); s_info[g_f] = (ra_f & 0xffu) | (cmf << 8); }
-        if (vr) { s_child[g_r] = make_uint4(cr.w[0], cr.w[1], cr.w[2], cr.w[3]); s_info[g_r] = (ra_r & 0xffu) | (cmr << 8); }
-        nb = (int)min(total_valid, (uint32_t)width);                             // :132 / :175
-        if (fast) {
-            // unique keys score * 512 + (511 - generation index): their descending order is the stable order of :131 / :174
-            const uint32_t kf = vf ? (eval_fast_u32_known(cf, nf, cmf) << 9) + (511u - g_f) : 0u;
-            const uint32_t kr = vr ? (eval_fast_u32_known(cr, nr, cmr) << 9) + (511u - g_r) : 0u;
-            const uint32_t slot = 511u - (top32_of_pair(kf, kr) & 511u);         // lane r < nb: slot of the rank-r child
-            const auto sq = __builtin_amdgcn_permlane32_swap(slot, slot, false, false);
-            q = sq[0];                                                           // {lower, lower}: lane 32 + r takes lane r's
-            best = uniform(slot);
-        } else {
-            const double sf = eval_full_known(cf, phase, nf, cmf), sr = eval_full_known(cr, phase, nr, cmr);
-            if (vf) s_score[g_f] = sf;
-            if (vr) s_score[g_r] = sr;
-            if (lane == 0u) s_score[total_valid] = -INFINITY;                    // the pair read below may look one slot past the end
-            __syncthreads();
-            uint32_t rank_f = 0u, rank_r = 0u;                                   // stable descending rank (:131, :174)
-            for (uint32_t j = 0; j < total_valid; j += 2) {
-                const double2 sj = *reinterpret_cast<const double2 *>(&s_score[j]);
-                rank_f += (sj.x > sf || (sj.x == sf && j < g_f)) ? 1u : 0u;
-                rank_f += (sj.y > sf || (sj.y == sf && j + 1 < g_f)) ? 1u : 0u;
-                rank_r += (sj.x > sr || (sj.x == sr && j < g_r)) ? 1u : 0u;
-                rank_r += (sj.y > sr || (sj.y == sr && j + 1 < g_r)) ? 1u : 0u;
-            }
-            if (vf && rank_f < (uint32_t)width) s_order[rank_f] = g_f;
-            if (vr && rank_r < (uint32_t)width) s_order[rank_r] = g_r;
-            __syncthreads();
-            q = s_order[(int)p < nb ? p : 0u];
-            best = uniform(q);                                                   // lane 0 holds rank 0's slot
-        }
-    }
-    const Decision d = {s_info[best] & 0xffu, 1.0f, expanded};                   // :178-181
-    __syncthreads();                                                            // read before the caller reuses the LDS
-    return d;
-}
+#ifdef G2048_BEAM_LANES
+#include "g2048_beam_lanes.inc"      // A/B only: the lane-resident formulation (bit-exact, measured slower; see the file's header)
+#endif
 
 // BeamSearchAgent.get_action for the game this wavefront owns. mask_in < 0: no caller mask. Every lane returns the same
 // Decision. Must be called by all 64 lanes (it contains workgroup barriers).
