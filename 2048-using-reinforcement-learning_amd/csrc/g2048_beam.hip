@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/g2048.h"
 #include "g2048_board.h"
@@ -32,6 +33,16 @@ constexpr int kSimdsPerCu = 4, kFallbackCus = 256;     // CDNA: four SIMDs per c
 //   order_min      the balanced order pays from four searches per SIMD on (at two it costs more than it gains);
 //   helper_cap     helper wavefronts never take more than a quarter of the wavefronts the chip holds at once (resident blocks
 //                  per CU x CUs / 4), so that owners find room whatever the dispatch order.
+// Internal flag of beam_decide (bits 0-1 are G2048_BEAM_FIXED_DOWN / RANK_BY_COUNTING): s_setprio by remaining levels.
+// Set by g2048_beam_get_action when every block of the launch is resident at once; with more blocks than the chip holds,
+// wavefronts that end together leave the rest of the grid to a burst dispatch on an emptied chip (8192 games: -10 %).
+constexpr uint32_t kFlagPrioByRemaining = 4u;
+#ifndef G2048_PRIO_T1
+#define G2048_PRIO_T1 2
+#define G2048_PRIO_T2 5
+#define G2048_PRIO_T3 10
+#endif
+constexpr int kPrioT1 = G2048_PRIO_T1, kPrioT2 = G2048_PRIO_T2, kPrioT3 = G2048_PRIO_T3;
 struct LaunchPlan { uint32_t order_row, order_min, helper_cap; };
 constexpr LaunchPlan launch_plan(int cus, int resident_blocks_per_cu)
 {
@@ -426,6 +437,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     const uint32_t lane = threadIdx.x;
     const bool fixed_down = (flags & 1u) != 0u;          // G2048_BEAM_FIXED_DOWN
     const bool count_rank = (flags & 2u) != 0u;          // G2048_BEAM_RANK_BY_COUNTING
+    const bool by_remaining = (flags & kFlagPrioByRemaining) != 0u;
 #ifdef G2048_BEAM_LANES
     // A/B only: the lane-resident formulation above for beams up to 32 wide. Bit-exact (the whole GPU suite passes on it), but
     // 11.6 % more vector instructions per decision and only 2 % less latency for a lone wavefront: 5.6 % slower at 4096 games,
@@ -473,6 +485,17 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
 
     for (int level = 0; level == 0 || level < actual_depth; ++level) {
         const bool fast = level == 0 || level > 3;             // :122, :139
+        if (by_remaining) {
+            // Issue priority by the levels this search still has to run. The SIMD's arbiter serves the oldest wavefront first:
+            // of four searches that share a SIMD the first runs at a lone wavefront's pace and is done after 60 % of the launch,
+            // the last ones then finish on a SIMD that holds one or two wavefronts (tools/beam_timeline.py). Longest-remaining-
+            // first keeps all of them on the SIMD until the last levels (profiles/r03_beam_priority.txt).
+            const int rem = actual_depth - level;
+            if (rem > kPrioT3) __builtin_amdgcn_s_setprio(3);
+            else if (rem > kPrioT2) __builtin_amdgcn_s_setprio(2);
+            else if (rem > kPrioT1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // ---- stage A
         uint32_t total_valid = 0;
         const int n_parents = level == 0 ? 1 : nb;
@@ -907,12 +930,24 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     const size_t g = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
     const uint4 rv = roots[g];
     const Board root = {{rv.x, rv.y, rv.z, rv.w}};
+#ifdef G2048_BEAM_TIMING
+    const unsigned long long tick0 = wall_clock64();                // tools/beam_timeline.py: when and where each search ran
+#endif
     const Decision d = beam_decide<PASSES>(sh, root, mask_in ? (int)(mask_in[g] & 15u) : -1, width, depth, early_thr, mid_thr,
                                            k0, k1, id_base + g, flags);
     if (threadIdx.x == 0) {
         action_out[g] = (uint8_t)d.action;
+#ifdef G2048_BEAM_TIMING
+        const uint32_t h = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+        // HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]  ->  13-bit SIMD number
+        const uint32_t simd = ((h >> 4) & 3u) | (((h >> 8) & 15u) << 2) | (((h >> 12) & 1u) << 6) | (((h >> 13) & 7u) << 7) | ((x & 15u) << 10);
+        const uint32_t dur = (uint32_t)(wall_clock64() - tick0);
+        prob_out[g] = __uint_as_float((uint32_t)tick0);
+        if (expanded_out) expanded_out[g] = (dur < 0x3ffffu ? dur : 0x3ffffu) | (simd << 18);
+#else
         prob_out[g] = d.prob;
         if (expanded_out) expanded_out[g] = d.expanded;
+#endif
     }
 }
 
@@ -992,6 +1027,10 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
 // would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
 // Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
+#ifndef G2048_PLAY_PRIO_OWNER
+#define G2048_PLAY_PRIO_OWNER 3
+#define G2048_PLAY_PRIO_HELPER 3
+#endif
 constexpr int kSpec = (int)kSpecSlotsPerGame;
 constexpr size_t kSpecMaxGames = 1u << 16;           // beyond this the workspace is not worth it: one wavefront per game
 constexpr uint32_t kNone = 0xffffffffu;
@@ -1071,6 +1110,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
     __shared__ uint4 s_req_board[kSpec];
     __shared__ uint32_t s_req_t[kSpec];
     if (blockIdx.x >= n_games) {
+        __builtin_amdgcn_s_setprio(G2048_PLAY_PRIO_HELPER);
         spec_helper<PASSES>(sh, ctl, reg_list, slots, n_games, width, depth, early_thr, mid_thr, seed, id_base, flags);
         return;
     }
@@ -1088,6 +1128,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
         if (!registered && (stuck >= stuck_thr || ((st.t & 31) == 0 && uniform(ld_relaxed(&ctl->resolved)) >= reg_resolved))) {
             if (lane == 0) st_release(&reg_list[atomicAdd(&ctl->registered, 1u)], (uint32_t)g);
             registered = true;
+            __builtin_amdgcn_s_setprio(G2048_PLAY_PRIO_OWNER);         // a registered game is on the run's critical path
         }
         const Keys ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const uint32_t draw = rng_draw(ks.k0, ks.k1, gid, 0u);
@@ -1166,6 +1207,28 @@ extern "C" {
 const char *g2048_last_error(void);
 void g2048_set_last_error_(const char *msg);
 
+// Blocks of beam_kernel<passes> the current device holds at once (occupancy x CUs), asked once per device and kernel.
+static size_t beam_resident_blocks(int passes)
+{
+    constexpr int kDevs = 64;
+    static std::atomic<uint32_t> cache[kDevs][4];                    // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) { (void)hipGetLastError(); return 0; }
+    const int pi = passes == 1 ? 0 : passes == 2 ? 1 : passes == 4 ? 2 : 3;
+    uint32_t v = cache[dev][pi].load(std::memory_order_relaxed);
+    if (v == 0u) {
+        int per_cu = 0;
+        const hipError_t e = pi == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, beam_kernel<1>, 64, 0)
+                           : pi == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, beam_kernel<2>, 64, 0)
+                           : pi == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, beam_kernel<4>, 64, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, beam_kernel<8>, 64, 0);
+        if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return 0; }
+        v = (uint32_t)per_cu * (uint32_t)device_cus();
+        cache[dev][pi].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
                      float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                      int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
@@ -1183,7 +1246,11 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)n_games);
     const uint4 *roots = static_cast<const uint4 *>(root_boards);
-    const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
+    uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
+#ifndef G2048_BEAM_NO_PRIO
+    // every block resident at once (4096 games on MI355X: four of the six a SIMD holds): issue priority by remaining levels
+    if (n_games <= beam_resident_blocks(width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8)) fd |= kFlagPrioByRemaining;
+#endif
     // with scratch for it, and a batch of at least four searches per SIMD, the blocks take the games in a depth-balanced order
     uint32_t *order = nullptr;
     const LaunchPlan plan = launch_plan(order_ws ? device_cus() : 0, 0);

@@ -302,3 +302,19 @@ def test_balanced_block_order_is_only_an_order(ops, n):
     with pytest.raises(RuntimeError, match="workspace"):
         L.call(roots.device, L.lib().g2048_beam_get_action_ws, roots.data_ptr(), None, a.data_ptr(), p.data_ptr(), None, 20, 6, 512,
                1024, L.u64(1), L.u64(0), L.u64(0), n, 0, small.data_ptr(), need - 4, L.stream_ptr(roots.device))
+
+
+def test_issue_priority_is_only_a_schedule(ops):
+    """A launch whose blocks are all resident at once raises and lowers each wavefront's issue priority with the levels it
+    has left (s_setprio; launches beyond what the chip holds do not). A schedule, not a result: one launch of 9000 games
+    (no priorities) equals the same games in pieces of 4096 + 4096 + 808 (with priorities), ids and draws kept."""
+    n = 9000
+    roots = torch.cat([ops.synth_boards(n // 2, seed=15, id_base=0, device=DEV),
+                       ops.synth_boards(n - n // 2, seed=16, id_base=0, p_empty=0.6, max_code=10, device=DEV)])
+    roots = roots[torch.randperm(n, generator=torch.Generator().manual_seed(9)).to(DEV)].contiguous()
+    a, p, e = ops.beam_get_action(roots, 20, 30, seed=91, step_index=7, game_id_base=300, want_expanded=True)
+    for lo in range(0, n, 4096):
+        hi = min(lo + 4096, n)
+        a1, p1, e1 = ops.beam_get_action(roots[lo:hi].contiguous(), 20, 30, seed=91, step_index=7, game_id_base=300 + lo,
+                                         want_expanded=True)
+        assert torch.equal(a[lo:hi], a1) and torch.equal(p[lo:hi], p1) and torch.equal(e[lo:hi], e1), lo
