@@ -967,8 +967,14 @@ struct GameState {
     bool alive;
 };
 
-__device__ __forceinline__ void game_apply(GameState &st, const StepOut &o, uint32_t expanded)
+// The state is the same in every lane; the step's outputs come off the vector unit, so they are taken through
+// v_readfirstlane: the whole GameState then lives in scalar registers (or their spill lanes), not in ~25 vector registers
+// held across the search: play_spec_kernel<2> 140 -> 102 vector registers, play_kernel<2> 122 -> 91.
+__device__ __forceinline__ void game_apply(GameState &st, const StepOut &ov, uint32_t expanded_v)
 {
+    const Board ob = {{uniform(ov.board.w[0]), uniform(ov.board.w[1]), uniform(ov.board.w[2]), uniform(ov.board.w[3])}};
+    const struct { Board board; uint32_t gain, flags; } o = {ob, uniform(ov.gain), uniform(ov.flags)};
+    const uint32_t expanded = uniform(expanded_v);
     st.b = o.board;
     st.sc += o.gain;
     st.expanded += expanded;
@@ -1006,7 +1012,8 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
     const uint4 rv = boards[g];
-    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    GameState st = {Board{{uniform(rv.x), uniform(rv.y), uniform(rv.z), uniform(rv.w)}}, uniform(score[g]),
+                    {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     while (st.t < max_moves && st.alive) {
         const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t), ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
@@ -1027,6 +1034,13 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
 // would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
 // Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
+// A/B: an occupancy request for the evaluation kernel, e.g. -D'G2048_PLAY_SPEC_WAVES=__attribute__((amdgpu_waves_per_eu(5,8)))'.
+// Left to the compiler (102 vector registers, four wavefronts per SIMD at width 20): with five or six per SIMD the helper
+// wavefronts are resident from the start and their speculation competes with 4096 running games -- 0.22 s / 0.25 s against
+// 0.20 s (profiles/r03_beam_priority.txt, section 8).
+#ifndef G2048_PLAY_SPEC_WAVES
+#define G2048_PLAY_SPEC_WAVES
+#endif
 #ifndef G2048_PLAY_PRIO_OWNER
 #define G2048_PLAY_PRIO_OWNER 3
 #define G2048_PLAY_PRIO_HELPER 3
@@ -1097,7 +1111,7 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
 }
 
 template <int PASSES>
-__global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
+__global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
                                                       int32_t *__restrict__ moves_out, int32_t *__restrict__ valid_out,
                                                       int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
                                                       unsigned long long *__restrict__ expanded_out,
@@ -1118,7 +1132,8 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
     const uint4 rv = boards[g];
-    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    GameState st = {Board{{uniform(rv.x), uniform(rv.y), uniform(rv.z), uniform(rv.w)}}, uniform(score[g]),
+                    {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     SpecSlot *const my = slots + g * kSpec;
     if (lane == 0) atomicAdd(&ctl->started, 1u);
     bool registered = false;
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
             const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
             const StepOut o = step_board(st.b, d.action, draw);
             game_apply(st, o, d.expanded);
-            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+            stuck = (uniform(o.flags) & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
         }
         while (on && st.alive && st.t < max_moves) {                 // decisions the helpers have made for where we are now
             const uint4 q = s_req_board[lane & (kSpec - 1)];
@@ -1187,7 +1202,7 @@ __global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ board
             const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
             const StepOut o = step_board(st.b, action, rng_draw(k2.k0, k2.k1, gid, 0u));
             game_apply(st, o, ex);
-            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+            stuck = (uniform(o.flags) & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
             on &= ~(1u << k);
         }
         __syncthreads();                                             // s_req_* are rewritten next round
@@ -1273,6 +1288,17 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     return G2048_OK;
 }
 
+static int play_resident_per_cu(int passes)          // blocks of play_spec_kernel<passes> a compute unit holds (0: could not ask)
+{
+    int resident = 0;
+    const hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, 0)
+                        : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, 0)
+                        : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, 0);
+    if (oe != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return resident;
+}
+
 static size_t play_workspace_bytes(size_t n_games)
 {
     const size_t list_bytes = (n_games * sizeof(uint32_t) + 63u) & ~(size_t)63u;
@@ -1319,15 +1345,7 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
         // posted result. Measured flat around these values (profiles/r02_eval_helpers.txt); g2048_play_games_tuned overrides
         // them for measurements and tests (every field clamped).
         const uint32_t n = (uint32_t)n_games;
-        int resident = 0;
-        {
-            hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, 0)
-                          : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, 0)
-                          : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, 0)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, 0);
-            if (oe != hipSuccess) { (void)hipGetLastError(); resident = 0; }
-        }
-        const LaunchPlan plan = launch_plan(device_cus(), resident);
+        const LaunchPlan plan = launch_plan(device_cus(), play_resident_per_cu(passes));
         uint32_t helpers = default_helpers(n, plan.helper_cap);
         uint32_t games_left = std::max<uint32_t>(n / 8u, 256u);
         int stuck_thr = 16;
@@ -1428,6 +1446,25 @@ int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_ga
     }
     const LaunchPlan p = launch_plan(compute_units ? compute_units : device_cus(), resident_blocks_per_cu);
     out4[0] = p.order_row; out4[1] = p.order_min; out4[2] = p.helper_cap; out4[3] = default_helpers((uint32_t)n_games, p.helper_cap);
+    return G2048_OK;
+}
+
+int g2048_device_plan(int width, size_t n_games, uint32_t *out6)
+{
+    if (!out6 || width < 1 || width > kMaxWidth || n_games > 0xffffffffu) {
+        g2048_set_last_error_("g2048_device_plan: bad arguments"); return G2048_ERR_ARG;
+    }
+    const int passes = width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8;
+    const int cus = device_cus(), resident = play_resident_per_cu(passes);
+    const LaunchPlan p = launch_plan(cus, resident);
+    const size_t beam_blocks = beam_resident_blocks(passes);
+    out6[0] = (uint32_t)cus; out6[1] = (uint32_t)resident; out6[2] = p.helper_cap;
+    out6[3] = default_helpers((uint32_t)n_games, p.helper_cap); out6[4] = (uint32_t)beam_blocks;
+#ifndef G2048_BEAM_NO_PRIO
+    out6[5] = n_games <= beam_blocks ? 1u : 0u;
+#else
+    out6[5] = 0u;
+#endif
     return G2048_OK;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "g2048_play_games_tuned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp,
                                      _sz, _vp, _vp]),
     "g2048_launch_plan": (_int, [_int, _int, _sz, _vp]),
+    "g2048_device_plan": (_int, [_int, _sz, _vp]),
     "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_unpack_i32": (_int, [_vp, _vp, _sz, _vp]),
     "g2048_synth_boards": (_int, [_vp, _u64, _u64, _sz, _u32, _u32, _vp]),

@@ -596,6 +596,17 @@ def launch_plan(compute_units=0, resident_blocks_per_cu=0, n_games=0):
     return dict(order_row=out[0], order_min_games=out[1], helper_cap=out[2], default_helpers=out[3])
 
 
+def device_plan(width=20, n_games=4096, device="cuda"):
+    """What the library asks the current device before a beam / evaluation launch (g2048_device_plan): dict(compute_units,
+    play_resident_blocks_per_cu, helper_cap, default_helpers, beam_resident_blocks, beam_issue_priority)."""
+    import ctypes
+    out = (ctypes.c_uint32 * 6)()
+    with torch.cuda.device(torch.device(device)):
+        L.check(L.lib().g2048_device_plan(int(width), int(n_games), ctypes.cast(out, ctypes.c_void_p)))
+    return dict(compute_units=out[0], play_resident_blocks_per_cu=out[1], helper_cap=out[2], default_helpers=out[3],
+                beam_resident_blocks=out[4], beam_issue_priority=bool(out[5]))
+
+
 def selftest(device="cuda"):
     r = torch.full((1,), 0xFFFF, dtype=torch.int32, device=device)
     L.call(r.device, L.lib().g2048_selftest, r.data_ptr(), L.stream_ptr(r.device))

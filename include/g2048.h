@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan; no env hook) */
+#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan; no env hook) */
 
 enum {
     G2048_OK = 0,
@@ -243,6 +243,12 @@ int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *m
  * the device holds at once: compute_units x resident_blocks_per_cu / 4), default helper wavefronts for n_games }.
  * compute_units = 0: the current device's count; resident_blocks_per_cu = 0: 32 (the hardware cap for 64-thread blocks). */
 int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_games, uint32_t *out4);
+
+/* What the library asks the CURRENT device before a beam / evaluation launch of this width and size (host only):
+ * out6 = { compute units, blocks of the evaluation kernel one compute unit holds (occupancy query), helper-wavefront cap,
+ * default helper wavefronts for n_games, blocks of the beam kernel the device holds at once, 1 if a g2048_beam_get_action
+ * launch of n_games runs with issue priority by remaining levels (every block resident at once), else 0 }. */
+int g2048_device_plan(int width, size_t n_games, uint32_t *out6);
 
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);

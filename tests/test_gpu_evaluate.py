@@ -288,3 +288,20 @@ def test_complete_games_vs_oracle_reference_configuration(g2048):
     for gid, score, moves, invalid, board in ref:
         assert res["scores"][gid] == score and res["moves"][gid] == moves and res["invalid_moves"][gid] == invalid, gid
         assert [int(x) for x in res["final_boards"][gid].reshape(-1)] == board, gid
+
+
+def test_device_plan_reports_what_a_launch_will_use():
+    """g2048_device_plan: the occupancy-derived numbers behind a launch (helper cap = a quarter of the evaluation kernel's
+    resident blocks, default helpers within it; a beam batch runs with issue priority iff it is resident at once)."""
+    import __graft_entry__ as ge
+    ge.import_package()
+    from g2048 import ops
+    p = ops.device_plan(20, 4096)
+    assert p["compute_units"] > 0 and p["play_resident_blocks_per_cu"] > 0
+    assert p["helper_cap"] == max(p["compute_units"] * p["play_resident_blocks_per_cu"] // 4, 1)
+    assert p["default_helpers"] == min(8 * 4096, max(4096 // 2, 1024), p["helper_cap"])
+    assert p["beam_resident_blocks"] % p["compute_units"] == 0 and p["beam_resident_blocks"] >= 4 * p["compute_units"]
+    assert p["beam_issue_priority"] == (4096 <= p["beam_resident_blocks"])
+    big = ops.device_plan(20, p["beam_resident_blocks"] + 1)
+    assert not big["beam_issue_priority"]
+    assert ops.device_plan(128, 64)["play_resident_blocks_per_cu"] <= p["play_resident_blocks_per_cu"]
