@@ -1038,6 +1038,10 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // Left to the compiler (102 vector registers, four wavefronts per SIMD at width 20): with five or six per SIMD the helper
 // wavefronts are resident from the start and their speculation competes with 4096 running games -- 0.22 s / 0.25 s against
 // 0.20 s (profiles/r03_beam_priority.txt, section 8).
+#ifndef G2048_PLAY_DYN_LDS
+#define G2048_PLAY_DYN_LDS 0
+#endif
+constexpr size_t kPlayDynLds = G2048_PLAY_DYN_LDS;      // unused LDS requested per block: caps the blocks a compute unit holds
 #ifndef G2048_PLAY_SPEC_WAVES
 #define G2048_PLAY_SPEC_WAVES
 #endif
@@ -1291,10 +1295,11 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
 static int play_resident_per_cu(int passes)          // blocks of play_spec_kernel<passes> a compute unit holds (0: could not ask)
 {
     int resident = 0;
-    const hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, 0)
-                        : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, 0)
-                        : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, 0)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, 0);
+    const size_t dyn = kPlayDynLds;
+    const hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, dyn)
+                        : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, dyn)
+                        : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, dyn)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, dyn);
     if (oe != hipSuccess) { (void)hipGetLastError(); return 0; }
     return resident;
 }
@@ -1374,7 +1379,7 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
             g2048_set_last_error_(hipGetErrorString(me)); return G2048_ERR_HIP;
         }
         const dim3 grid((unsigned)(n + helpers));
-#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
+#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), kPlayDynLds, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
                                                 stuck_thr, reg_resolved, wait_us * 100u)
         if (passes == 1) G2048_LAUNCH_PLAY(1);
         else if (passes == 2) G2048_LAUNCH_PLAY(2);
