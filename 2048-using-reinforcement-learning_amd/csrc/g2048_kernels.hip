@@ -93,6 +93,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                                                      uint64_t id_base, size_t n, const uint32_t *__restrict__ keyblock,
                                                      uint32_t a0 = 0, uint32_t a1 = 0)
 {
+    // Streaming launches (two boards per lane, from 4 Mi boards on): a new wavefront issues its loads ahead of the arithmetic of
+    // the older ones on its SIMD (the arbiter would serve those first) -- 152.8 -> 147.5 us per 16 Mi boards. Nothing to gain at
+    // 1 Mi boards, where five phase-priority schemes stayed within +-1 % (profiles/r03_beam_priority.txt, section 10).
+    if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
     dir_table_to_lds(s_dir);
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
             sc[k] = scp[j];
         }
     }
+    if (B > 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < B; ++k) {
         const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
