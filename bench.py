@@ -470,8 +470,9 @@ def main():
                                                  "(16 B in, 5 B out per decision), so this is a comparability figure, not traffic",
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
                           "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
-                                    "a bitonic network over the lanes; a 4.5 us beam_order_kernel deals the games to the SIMDs by depth "
-                                    "first -- its time is inside ms_per_batch_decision)"}
+                                    "a bitonic network over the lanes; issue priority by remaining levels while the whole launch is resident; "
+                                    "a 5 us beam_order_kernel deals the games to the SIMDs by depth first -- its time is inside "
+                                    "ms_per_batch_decision)"}
         # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
         # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
         # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
