@@ -957,7 +957,11 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
 // is reached, with the per-move bookkeeping (milestones, valid / invalid counters) in registers. No launch, no host,
 // no other game is involved between two moves; draws are the ones the step-by-step driver uses -- move t of game g
 // takes (seed, BEAM, t, g, j) for the search and (seed, STEP, t, g) for the spawn -- so the results are identical.
-// Per-game bookkeeping of the evaluation loop (evaluate_beam_search.py:48-69), identical in every lane.
+// Per-game bookkeeping of the evaluation loop (evaluate_beam_search.py:48-69), identical in every lane and kept in vector
+// registers. Two other homes for it were built and measured (profiles/r03_beam_priority.txt, section 8): scalar registers
+// (every step output through v_readfirstlane: play_spec_kernel<2> 140 -> 102 vector registers, four wavefronts per SIMD
+// instead of three, but 126 spilled scalars) and LDS (lane 0 updates a 52-byte record once per move: 106 registers) -- both
+// 0.200 s for the 4096-game evaluation against 0.1975 s like this, so the plain form stays.
 struct GameState {
     Board b;
     uint32_t sc;
@@ -967,14 +971,8 @@ struct GameState {
     bool alive;
 };
 
-// The state is the same in every lane; the step's outputs come off the vector unit, so they are taken through
-// v_readfirstlane: the whole GameState then lives in scalar registers (or their spill lanes), not in ~25 vector registers
-// held across the search: play_spec_kernel<2> 140 -> 102 vector registers, play_kernel<2> 122 -> 91.
-__device__ __forceinline__ void game_apply(GameState &st, const StepOut &ov, uint32_t expanded_v)
+__device__ __forceinline__ void game_apply(GameState &st, const StepOut &o, uint32_t expanded)
 {
-    const Board ob = {{uniform(ov.board.w[0]), uniform(ov.board.w[1]), uniform(ov.board.w[2]), uniform(ov.board.w[3])}};
-    const struct { Board board; uint32_t gain, flags; } o = {ob, uniform(ov.gain), uniform(ov.flags)};
-    const uint32_t expanded = uniform(expanded_v);
     st.b = o.board;
     st.sc += o.gain;
     st.expanded += expanded;
@@ -1012,8 +1010,7 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
     const uint4 rv = boards[g];
-    GameState st = {Board{{uniform(rv.x), uniform(rv.y), uniform(rv.z), uniform(rv.w)}}, uniform(score[g]),
-                    {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     while (st.t < max_moves && st.alive) {
         const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t), ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
@@ -1136,8 +1133,7 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
     const uint4 rv = boards[g];
-    GameState st = {Board{{uniform(rv.x), uniform(rv.y), uniform(rv.z), uniform(rv.w)}}, uniform(score[g]),
-                    {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
+    GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     SpecSlot *const my = slots + g * kSpec;
     if (lane == 0) atomicAdd(&ctl->started, 1u);
     bool registered = false;
@@ -1189,7 +1185,7 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
             const StepOut o = step_board(st.b, d.action, draw);
             game_apply(st, o, d.expanded);
-            stuck = (uniform(o.flags) & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
         }
         while (on && st.alive && st.t < max_moves) {                 // decisions the helpers have made for where we are now
             const uint4 q = s_req_board[lane & (kSpec - 1)];
@@ -1206,7 +1202,7 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
             const StepOut o = step_board(st.b, action, rng_draw(k2.k0, k2.k1, gid, 0u));
             game_apply(st, o, ex);
-            stuck = (uniform(o.flags) & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+            stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
             on &= ~(1u << k);
         }
         __syncthreads();                                             // s_req_* are rewritten next round
