@@ -1340,7 +1340,8 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
 #undef G2048_LAUNCH_PLAY
     } else {
         // Helpers: eight per game for a small batch, half the games for a large one, never more than a quarter of the
-        // wavefronts the device holds at once (launch_plan: CUs x resident blocks per CU / 4 -- 2048 on a whole MI355X), so
+        // wavefronts the device holds of this kernel at once (launch_plan: CUs x resident blocks per CU / 4 -- 768 on a whole
+        // MI355X at width 20, where the kernel's 140 vector registers allow 12 blocks per CU; g2048_device_plan reports it), so
         // owners always find room whatever the dispatch order. A game registers for them once it is stuck (16 more invalid
         // than valid moves lately) or once an eighth of the games (at least 256) is left; an owner polls at most 150 us for a
         // posted result. Measured flat around these values (profiles/r02_eval_helpers.txt); g2048_play_games_tuned overrides
