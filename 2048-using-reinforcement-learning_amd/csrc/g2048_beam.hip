@@ -1136,6 +1136,11 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
     GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     SpecSlot *const my = slots + g * kSpec;
     if (lane == 0) atomicAdd(&ctl->started, 1u);
+#ifdef G2048_PLAY_TIMING      // tools/play_timeline.py: the milestone record carries when / where the game ran instead
+    const uint32_t tm_start = (uint32_t)wall_clock64();
+    int32_t tm_reg_t = -1, tm_searches = 0, tm_hits = 0, tm_late = 0;
+    uint32_t tm_reg_tick = 0u;
+#endif
     bool registered = false;
     uint32_t seq = 0u;
     int stuck = 0;                                                   // invalid moves minus valid ones, floored at 0
@@ -1144,6 +1149,9 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             if (lane == 0) st_release(&reg_list[atomicAdd(&ctl->registered, 1u)], (uint32_t)g);
             registered = true;
             __builtin_amdgcn_s_setprio(G2048_PLAY_PRIO_OWNER);         // a registered game is on the run's critical path
+#ifdef G2048_PLAY_TIMING
+            tm_reg_t = st.t; tm_reg_tick = (uint32_t)wall_clock64();
+#endif
         }
         const Keys ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const uint32_t draw = rng_draw(ks.k0, ks.k1, gid, 0u);
@@ -1186,6 +1194,9 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             const StepOut o = step_board(st.b, d.action, draw);
             game_apply(st, o, d.expanded);
             stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
+#ifdef G2048_PLAY_TIMING
+            if (registered) ++tm_searches;
+#endif
         }
         while (on && st.alive && st.t < max_moves) {                 // decisions the helpers have made for where we are now
             const uint4 q = s_req_board[lane & (kSpec - 1)];
@@ -1197,6 +1208,9 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             const unsigned long long t0 = wall_clock64();
             bool ready;
             while (!(ready = uniform(ld_acquire(&my[k].res_seq)) == seq) && wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
+#ifdef G2048_PLAY_TIMING
+            if (!ready) ++tm_late; else ++tm_hits;
+#endif
             if (!ready) break;                                       // a late helper: search this move ourselves
             const uint32_t action = uniform(ld_relaxed(&my[k].res_action)), ex = uniform(ld_relaxed(&my[k].res_expanded));
             const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
@@ -1210,6 +1224,10 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
     if (lane < (uint32_t)kSpec) st_release(&my[lane].seq, kNone);
     if (lane == 0) {
         game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
+#ifdef G2048_PLAY_TIMING
+        milestone_out[2 * g] = make_int4((int)tm_start, (int)(uint32_t)wall_clock64(), tm_reg_t, (int)tm_reg_tick);
+        milestone_out[2 * g + 1] = make_int4(tm_searches, tm_hits, tm_late, 0);
+#endif
         atomicAdd(&ctl->resolved, 1u);
     }
 }
