@@ -96,6 +96,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     // Streaming launches (two boards per lane, from 4 Mi boards on): a new wavefront issues its loads ahead of the arithmetic of
     // the older ones on its SIMD (the arbiter would serve those first) -- 152.8 -> 147.5 us per 16 Mi boards. Nothing to gain at
     // 1 Mi boards, where five phase-priority schemes stayed within +-1 % (profiles/r03_beam_priority.txt, section 10).
+#ifdef G2048_STEP_TIMING          // tools/step_timeline.py: lanes 0..2 of every wavefront write start tick, end tick and SIMD over the reward
+    const unsigned long long tm0 = wall_clock64();
+#endif
     if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
@@ -147,6 +150,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         if (REWARD_F64) rw64[j] = o.reward;
         else rw32[j] = (float)o.reward;
         flp[j] = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
+#ifdef G2048_STEP_TIMING
+        if (!REWARD_F64 && k == 0) {
+            const uint32_t h = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+            const uint32_t simd = ((h >> 4) & 3u) | (((h >> 8) & 15u) << 2) | (((h >> 12) & 1u) << 6) | (((h >> 13) & 7u) << 7) | ((x & 15u) << 10);
+            const uint32_t l = threadIdx.x & 63u;
+            if (l < 3u) reinterpret_cast<uint32_t *>(rw32)[j] = l == 0u ? (uint32_t)tm0 : l == 1u ? (uint32_t)wall_clock64() : simd;
+        }
+#endif
     }
 }
 
