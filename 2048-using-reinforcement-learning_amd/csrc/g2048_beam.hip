@@ -917,24 +917,113 @@ __global__ __launch_bounds__(1024) void beam_order_kernel(const uint4 *__restric
     }
 }
 
+// ---------------------------------------------------------------- the order of the previous call
+// beam_order_kernel costs a launch of its own in front of every batch (4.9 us of a 104 us call at 4096 games). Callers that
+// search batch after batch (an evaluation loop, the benchmark) can do without it: every block of call e drops its game into a
+// per-class list (one atomic ticket at its start, one store at its end), and call e + 1 deals the games from those lists --
+// the order of the PREVIOUS batch's roots. Any permutation gives the same results; this one is balanced to the extent that a
+// game's depth class survives one move (always, in the benchmark; nearly always, in an evaluation loop). The caller passes
+// the history buffer (zero-filled before its first use and whenever a call is not the successor of the last one that used it)
+// and a call index that counts up from 1.
+// Tickets: 4096 blocks asking one counter for a ticket at the same moment queue for ~10 ns each -- and the other memory
+// requests of their compute unit queue behind them (a quarter of the blocks started up to 45 us late, measured). So every
+// class has kHistSubs counters, chosen by the block index, each in a 128-byte line of its own (~100 tickets per counter),
+// and a class's list is kHistSubs segments of ceil(n / kHistSubs) entries.
+// Layout (32-bit words): two headers {magic, n, call} that alternate (a line each); three counter sets of 3 x kHistSubs
+// lines that rotate (this call counts in one, reads the previous one, clears the next); two sets of lists.
+constexpr uint32_t kHistMagic = 0x32303438u, kHistLine = 32u, kHistSubs = 16u, kHistHdr = kHistLine;
+constexpr uint32_t kHistCnt = 2u * kHistLine, kHistSet = 3u * kHistSubs * kHistLine, kHistLists = kHistCnt + 3u * kHistSet;
+__host__ __device__ constexpr uint32_t hist_seg(uint32_t n) { return (n + kHistSubs - 1u) / kHistSubs; }
+constexpr size_t hist_words(size_t n) { return kHistLists + 2u * 3u * kHistSubs * (size_t)hist_seg((uint32_t)n); }
+
+__device__ __forceinline__ size_t hist_lookup(const uint32_t *hist, uint32_t call_index, uint32_t n, int depth, uint32_t row_len,
+                                              uint32_t b)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *hp = hist + ((call_index - 1u) & 1u) * kHistHdr;                 // written by the previous call, not by this one
+    const uint32_t *cp = hist + kHistCnt + ((call_index - 1u) % 3u) * kHistSet;
+    const uint32_t magic = uniform(hp[0]), hn = uniform(hp[1]), hc = uniform(hp[2]);
+    // lane 16 c + s holds the tickets given out by counter s of class c; inclusive sums along each row of 16 lanes
+    uint32_t v = lane < 3u * kHistSubs ? cp[lane * kHistLine] : 0u;
+    v = v > n ? n + 1u : v;                                                           // (garbage cannot wrap the sums)
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < (int)kHistSubs; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, (int)kHistSubs);
+        if ((lane & (kHistSubs - 1u)) >= (uint32_t)d) incl += up;
+    }
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), c1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+    const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
+    if (magic != kHistMagic || hn != n || hc != call_index - 1u || c0 > n || c1 > n || c2 > n || c0 + c1 + c2 != n) return b;
+    // cost order of the classes as in beam_order_kernel: heaviest first, ties keep class order
+    const int d0 = depth, d1 = min(depth + 5, 25), d2 = min(depth - 5, 10);
+    const uint32_t r0 = (d1 > d0 ? 1u : 0u) + (d2 > d0 ? 1u : 0u), r1 = (d0 >= d1 ? 1u : 0u) + (d2 > d1 ? 1u : 0u);
+    const uint32_t r2 = (d0 >= d2 ? 1u : 0u) + (d1 >= d2 ? 1u : 0u);
+    const uint32_t start0 = (r1 < r0 ? c1 : 0u) + (r2 < r0 ? c2 : 0u), start1 = (r0 < r1 ? c0 : 0u) + (r2 < r1 ? c2 : 0u);
+    const uint32_t start2 = (r0 < r2 ? c0 : 0u) + (r1 < r2 ? c1 : 0u);
+    // block b sits in row b / row_len of the deal; odd rows run backwards
+    const uint32_t rows = (n + row_len - 1u) / row_len, row = b / row_len, q1 = b - row * row_len;
+    const uint32_t len = row + 1u == rows ? n - row * row_len : row_len;
+    const uint32_t r = row * row_len + ((row & 1u) ? len - 1u - q1 : q1);
+    uint32_t cls, idx;
+    if (r >= start0 && r - start0 < c0) { cls = 0u; idx = r - start0; }
+    else if (r >= start1 && r - start1 < c1) { cls = 1u; idx = r - start1; }
+    else { cls = 2u; idx = r - start2; }
+    // the segment of class cls that holds its idx-th game: the first counter whose inclusive sum exceeds idx
+    const unsigned long long over = __ballot((lane >> 4) == cls && lane < 3u * kHistSubs && incl > idx);
+    if (!over) return b;
+    const uint32_t at = (uint32_t)__builtin_ctzll(over);                              // lane 16 cls + sub
+    const uint32_t before = uniform((uint32_t)__shfl((int)(incl - v), (int)at, 64));   // (uniform: the search must not see a per-lane game id)
+    const uint32_t k = idx - before, seg = hist_seg(n);
+    if (k >= seg) return b;
+    const uint32_t g = uniform(hist[kHistLists + ((size_t)((call_index - 1u) & 1u) * 3u * kHistSubs + at) * seg + k]);
+    return g < n ? g : b;
+}
+
 template <int PASSES>
 __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ roots, const uint8_t *__restrict__ mask_in,
                                                  uint8_t *__restrict__ action_out, float *__restrict__ prob_out,
                                                  uint32_t *__restrict__ expanded_out, int width, int depth,
                                                  uint32_t early_thr, uint32_t mid_thr, uint32_t k0, uint32_t k1,
                                                  uint64_t id_base, uint32_t flags, const uint32_t *__restrict__ keyblock,
-                                                 const uint32_t *__restrict__ order)
+                                                 const uint32_t *__restrict__ order, uint32_t *hist, uint32_t call_index,
+                                                 uint32_t row_len)
 {
     if (keyblock) { k0 = keyblock[4]; k1 = keyblock[5]; }            // KB_BEAM of the device key block
     __shared__ BeamShared<PASSES> sh;
-    const size_t g = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
+    size_t g = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
+    const uint32_t n = gridDim.x;
+    if (hist) g = uniform((uint32_t)hist_lookup(hist, call_index, n, depth, row_len, blockIdx.x));
     const uint4 rv = roots[g];
     const Board root = {{rv.x, rv.y, rv.z, rv.w}};
+    // this game's place in the order of the NEXT call: a ticket inside its cost class now, the list entry when the search is done
+    const int mask_arg = mask_in ? (int)(mask_in[g] & 15u) : -1;                // (loaded before the ticket is asked for: vmcnt counts in order)
+    const uint32_t hist_cls = hist ? uniform(depth_class(rv)) : 0u;             // (scalar: nothing but the ticket is held in a vector register)
+    uint32_t hist_idx = 0u;
+    if (hist && threadIdx.x == 0) {
+        // The ticket is not needed before the search is over. The word offset goes through an opaque vector register: with an
+        // address it can prove uniform the compiler's atomic optimizer rewrites this into count-the-lanes + one atomic +
+        // s_waitcnt + v_readfirstlane, i.e. it waits at once -- 4096 blocks then queue on three counters for 48 us.
+        uint32_t woff = kHistCnt + (call_index % 3u) * kHistSet + (hist_cls * kHistSubs + (blockIdx.x & (kHistSubs - 1u))) * kHistLine;
+        asm volatile("" : "+v"(woff));
+        hist_idx = atomicAdd(&hist[woff], 1u);
+    }
+    if (hist && blockIdx.x == 0 && threadIdx.x < 3u * kHistSubs)     // the counters the call after the next one will count in
+        hist[kHistCnt + ((call_index + 1u) % 3u) * kHistSet + threadIdx.x * kHistLine] = 0u;
 #ifdef G2048_BEAM_TIMING
     const unsigned long long tick0 = wall_clock64();                // tools/beam_timeline.py: when and where each search ran
 #endif
-    const Decision d = beam_decide<PASSES>(sh, root, mask_in ? (int)(mask_in[g] & 15u) : -1, width, depth, early_thr, mid_thr,
-                                           k0, k1, id_base + g, flags);
+    const Decision d = beam_decide<PASSES>(sh, root, mask_arg, width, depth, early_thr, mid_thr, k0, k1, id_base + g, flags);
+    if (hist && threadIdx.x == 0) {
+        const uint32_t seg = hist_seg(n);
+        if (hist_idx < seg)
+            hist[kHistLists + ((size_t)(call_index & 1u) * 3u * kHistSubs + hist_cls * kHistSubs + (blockIdx.x & (kHistSubs - 1u))) * seg +
+                 hist_idx] = (uint32_t)g;
+        if (blockIdx.x == 0) {                                       // (only read by the next call, i.e. after this kernel)
+            uint32_t *h = hist + (call_index & 1u) * kHistHdr;
+            h[0] = kHistMagic; h[1] = n; h[2] = call_index;
+        }
+    }
     if (threadIdx.x == 0) {
         action_out[g] = (uint8_t)d.action;
 #ifdef G2048_BEAM_TIMING
@@ -1266,7 +1355,7 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
                      float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                      int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
                      uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, const uint32_t *keyblock,
-                     uint32_t *order_ws = nullptr)
+                     uint32_t *order_ws = nullptr, uint32_t *hist = nullptr, uint32_t call_index = 0)
 {
     if (n_games == 0) return G2048_OK;
     if (!root_boards || !action_out || !prob_out) { g2048_set_last_error_("g2048_beam_get_action: null pointer"); return G2048_ERR_ARG; }
@@ -1286,15 +1375,16 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
 #endif
     // with scratch for it, and a batch of at least four searches per SIMD, the blocks take the games in a depth-balanced order
     uint32_t *order = nullptr;
-    const LaunchPlan plan = launch_plan(order_ws ? device_cus() : 0, 0);
-    if (order_ws && n_games >= plan.order_min && n_games <= kOrderMaxGames) {
+    const LaunchPlan plan = launch_plan((order_ws || hist) ? device_cus() : 0, 0);
+    if (hist && !(n_games >= plan.order_min && n_games <= kOrderMaxGames)) hist = nullptr;
+    if (order_ws && !hist && n_games >= plan.order_min && n_games <= kOrderMaxGames) {
         order = order_ws;
         hipLaunchKernelGGL(beam_order_kernel, dim3(1), dim3(1024), 0, s, roots, order, (uint32_t)n_games, depth, plan.order_row);
     }
     {
 #define G2048_LAUNCH_BEAM(P) hipLaunchKernelGGL(beam_kernel<P>, grid, dim3(64), 0, s, roots, valid_mask_or_null, action_out, prob_out, \
                            expanded_out_or_null, width, depth, (uint32_t)early_threshold, (uint32_t)mid_threshold, \
-                           k.k0, k.k1, game_id_base, fd, keyblock, order)
+                           k.k0, k.k1, game_id_base, fd, keyblock, order, hist, call_index, plan.order_row)
         if (width <= 16) G2048_LAUNCH_BEAM(1);
         else if (width <= 32) G2048_LAUNCH_BEAM(2);
         else if (width <= 64) G2048_LAUNCH_BEAM(4);
@@ -1530,6 +1620,27 @@ int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_
     return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
                      mid_threshold, seed, step_index, game_id_base, n_games, opts, stream, nullptr,
                      need ? static_cast<uint32_t *>(workspace) : nullptr);
+}
+
+size_t g2048_beam_history_bytes(size_t n_games)
+{
+    return (n_games >= launch_plan(device_cus(), 0).order_min && n_games <= kOrderMaxGames) ? hist_words(n_games) * sizeof(uint32_t) : 0;
+}
+
+int g2048_beam_get_action_hist(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                               float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                               int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                               uint64_t game_id_base, size_t n_games, uint32_t opts, void *history, size_t history_bytes,
+                               uint32_t call_index, void *stream)
+{
+    const size_t need = g2048_beam_history_bytes(n_games);
+    if (history && need && (history_bytes < need || (reinterpret_cast<uintptr_t>(history) & 3u) || call_index == 0u)) {
+        g2048_set_last_error_("g2048_beam_get_action_hist: history smaller than g2048_beam_history_bytes(n_games), misaligned, or call_index 0");
+        return G2048_ERR_ARG;
+    }
+    return beam_impl(root_boards, valid_mask_or_null, action_out, prob_out, expanded_out_or_null, width, depth, early_threshold,
+                     mid_threshold, seed, step_index, game_id_base, n_games, opts, stream, nullptr, nullptr,
+                     (history && need) ? static_cast<uint32_t *>(history) : nullptr, call_index);
 }
 
 int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "g2048_beam_get_action": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _u64, _u64, _u64, _sz, _u32, _vp]),
     "g2048_beam_workspace_bytes": (_sz, [_sz]),
     "g2048_beam_get_action_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _u64, _u64, _u64, _sz, _u32, _vp, _sz, _vp]),
+    "g2048_beam_history_bytes": (_sz, [_sz]),
+    "g2048_beam_get_action_hist": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _u64, _u64, _u64, _sz, _u32, _vp, _sz, _u32, _vp]),
     "g2048_track_episodes": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _sz, _vp]),
     "g2048_sample_actions": (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_simulate_move": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -500,6 +500,7 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
 
 
 _BEAM_WS = {}
+_BEAM_HIST = {}     # (device, stream) -> [history tensor, batch size, calls so far]
 
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
@@ -507,8 +508,10 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
                     rank_by_counting=False, balanced_order=True,
                     out=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
-    Returns (actions uint8, probs float32[, expanded int32]). balanced_order: from 4096 roots on, let the blocks take the
-    games in a depth-balanced order (same results, shorter launch; needs 4 bytes of scratch per game, kept per stream)."""
+    Returns (actions uint8, probs float32[, expanded int32]). balanced_order: from 4096 roots on the blocks take the games in
+    a depth-balanced order (same results, shorter launch): True = the order the previous call on this stream left behind
+    (no launch of its own; the first call of a sequence runs in caller order), "sort" = an order from this call's own
+    roots (one more small launch), False = caller order. Scratch is kept per (device, stream)."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
     n = roots.shape[0]
     if not (1 <= int(width) <= L.BEAM_MAX_WIDTH):
@@ -532,18 +535,37 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
     else:
-        # scratch for the depth-balanced block order (large batches): caller-owned like every other buffer; one tensor per
-        # (device, stream), reused by later calls, which that stream orders (not while the stream is being captured: the
-        # cached tensor must not come from a graph's private pool)
-        need = 0 if (not balanced_order or torch.cuda.is_current_stream_capturing()) else int(L.lib().g2048_beam_workspace_bytes(n))
-        ws = None
-        if need:
-            key = (dev.index, tail[-1])
-            ws = _BEAM_WS.get(key)
-            if ws is None or ws.numel() < need:
-                ws = _BEAM_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
-        L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
-               ws.data_ptr() if ws is not None else None, need, tail[-1])
+        # the depth-balanced block order of large batches. Default: the order of the PREVIOUS call on this stream (its blocks
+        # file their games into a history buffer, g2048_beam_get_action_hist -- no launch of its own); the buffer is caller-owned
+        # like every other one: one zero-filled tensor per (device, stream), zeroed again when the batch size changes. With
+        # balanced_order="sort" the order comes from this call's own roots (beam_order_kernel, one more launch). Neither while the
+        # stream is being captured: the cached tensor must not come from a graph's private pool.
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (dev.index, tail[-1])
+        if balanced_order == "sort":
+            need = 0 if capturing else int(L.lib().g2048_beam_workspace_bytes(n))
+            ws = None
+            if need:
+                ws = _BEAM_WS.get(key)
+                if ws is None or ws.numel() < need:
+                    ws = _BEAM_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+            L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
+                   ws.data_ptr() if ws is not None else None, need, tail[-1])
+        else:
+            need = 0 if (not balanced_order or capturing) else int(L.lib().g2048_beam_history_bytes(n))
+            hist, call_index = None, 0
+            if need:
+                st = _BEAM_HIST.get(key)
+                if st is None or st[0].numel() < need or st[1] != n:
+                    buf = st[0] if (st is not None and st[0].numel() >= need) else torch.empty(need, dtype=torch.uint8, device=dev)
+                    buf.zero_()
+                    st = _BEAM_HIST[key] = [buf, n, 0]
+                st[2] += 1
+                if st[2] >= 0x7fffffff:
+                    st[0].zero_(); st[2] = 1
+                hist, call_index = st[0], st[2]
+            L.call(dev, L.lib().g2048_beam_get_action_hist, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
+                   hist.data_ptr() if hist is not None else None, need, call_index, tail[-1])
     return (actions, probs, expanded) if (want_expanded or (out is not None and expanded is not None)) else (actions, probs)
 
 

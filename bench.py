@@ -461,7 +461,8 @@ def main():
         beam_mean = sum(x / t for t, x in batches) / len(batches)
         result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games)",
                           "value": total_exp / bsec, "unit": "expansions/s", "value_mean_of_3_batches": beam_mean,
-                          "timing": "HIP event pair around 20 calls queued back to back (order kernel + beam kernel each); best of three "
+                          "timing": "HIP event pair around 20 calls queued back to back (one beam kernel each; the blocks take the games in the "
+                                    "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); best of three "
                                     "such batches (rounds 1-2: one batch), their mean beside it",
                           "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
                           "gbs_equivalent_29B": total_exp / bsec * BEAM_BYTES_PER_EXPANSION / 1e9,
@@ -471,8 +472,8 @@ def main():
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
                           "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
                                     "a bitonic network over the lanes; issue priority by remaining levels while the whole launch is resident; "
-                                    "a 5 us beam_order_kernel deals the games to the SIMDs by depth first -- its time is inside "
-                                    "ms_per_batch_decision)"}
+                                    "games dealt to the SIMDs by depth class from the lists the previous call's blocks filed them in "
+                                    "-- no order kernel)"}
         # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
         # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
         # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan; no env hook) */
+#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan, g2048_beam_get_action_hist; no env hook) */
 
 enum {
     G2048_OK = 0,
@@ -164,6 +164,20 @@ int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_
                              int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
                              uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* The same order without its own launch, for callers that search batch after batch (an evaluation loop): every block of a
+ * call files its game into per-class lists in `history`, and the NEXT call deals the games from them -- the balanced order of
+ * the previous batch's roots (any order gives the same results; this one is balanced as far as a game keeps its depth class
+ * from one call to the next). history: g2048_beam_history_bytes(n_games) bytes of device memory, ZERO-FILLED before its first
+ * use and again whenever a call is not the direct successor (call_index + 1, same n_games, same buffer, stream-ordered after
+ * it) of the last call that used it; call_index counts 1, 2, 3, ... . A call that finds no usable history takes the games in
+ * caller order. history NULL, or a batch for which the query returns 0: exactly g2048_beam_get_action. One buffer serves one
+ * stream of calls; it must not be shared by calls that may run concurrently. */
+size_t g2048_beam_history_bytes(size_t n_games);
+int g2048_beam_get_action_hist(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+                               float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
+                               int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
+                               uint64_t game_id_base, size_t n_games, uint32_t opts, void *history, size_t history_bytes,
+                               uint32_t call_index, void *stream);
 
 /* Per-move bookkeeping of the reference's evaluation loops (evaluate_beam_search.py:42-64, run_evaluation.py:56-69)
  * for n games after a g2048_step: for games still alive, milestone_move_inout[i][k] (k = 0..7 for tiles 64..8192,

@@ -292,8 +292,11 @@ def test_balanced_block_order_is_only_an_order(ops, n):
         a1, p1, e1 = ops.beam_get_action(roots, 20, depth, seed=77, step_index=3, game_id_base=1000, want_expanded=True,
                                          balanced_order=False)
         assert torch.equal(a, a1) and torch.equal(p, p1) and torch.equal(e, e1), depth
+        a2, p2, e2 = ops.beam_get_action(roots, 20, depth, seed=77, step_index=3, game_id_base=1000, want_expanded=True,
+                                         balanced_order="sort")            # beam_order_kernel on this call's own roots
+        assert torch.equal(a, a2) and torch.equal(p, p2) and torch.equal(e, e2), depth
     mask = torch.randint(0, 16, (n,), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).to(DEV)      # caller masks too
-    am, pm = ops.beam_get_action(roots, 20, 6, mask, seed=78, step_index=4, game_id_base=5)
+    am, pm = ops.beam_get_action(roots, 20, 6, mask, seed=78, step_index=4, game_id_base=5, balanced_order="sort")
     am1, pm1 = ops.beam_get_action(roots, 20, 6, mask, seed=78, step_index=4, game_id_base=5, balanced_order=False)
     assert torch.equal(am, am1) and torch.equal(pm, pm1)
     need = int(L.lib().g2048_beam_workspace_bytes(n))
@@ -318,3 +321,47 @@ def test_issue_priority_is_only_a_schedule(ops):
         a1, p1, e1 = ops.beam_get_action(roots[lo:hi].contiguous(), 20, 30, seed=91, step_index=7, game_id_base=300 + lo,
                                          want_expanded=True)
         assert torch.equal(a[lo:hi], a1) and torch.equal(p[lo:hi], p1) and torch.equal(e[lo:hi], e1), lo
+
+
+def test_order_of_the_previous_call_is_only_an_order(ops, oracle):
+    """Default for large batches: the blocks of a call file their games into per-class lists (g2048_beam_get_action_hist) and the
+    NEXT call on the stream deals the games from them -- no order kernel. A sequence of calls with DIFFERENT roots, a change of
+    the batch size in between, depths whose class costs order differently: every call equals the caller-order run; and the
+    first batch against the oracle."""
+    from g2048 import _lib as L
+    gen = torch.Generator().manual_seed(44)
+    def batch(n, k):
+        r = torch.cat([ops.synth_boards(n // 3, seed=50 + k, id_base=0, device=DEV),
+                       ops.synth_boards(n // 3, seed=60 + k, id_base=0, p_empty=0.7, max_code=9, device=DEV),
+                       ops.synth_boards(n - 2 * (n // 3), seed=70 + k, id_base=0, p_empty=0.1, device=DEV)])
+        return r[torch.randperm(n, generator=gen).to(DEV)].contiguous()
+    k = 0
+    for n, depth in ((4096, 30), (4096, 30), (4096, 6), (5000, 30), (5000, 30), (5000, 6), (4096, 30), (9300, 12), (9300, 12)):
+        roots = batch(n, k)
+        a, p, e = ops.beam_get_action(roots, 20, depth, seed=81, step_index=k, game_id_base=7 * k, want_expanded=True)
+        a1, p1, e1 = ops.beam_get_action(roots, 20, depth, seed=81, step_index=k, game_id_base=7 * k, want_expanded=True,
+                                         balanced_order=False)
+        assert torch.equal(a, a1) and torch.equal(p, p1) and torch.equal(e, e1), (k, n, depth)
+        if k == 1:
+            oa, op, oe = oracle.beam_batch(roots[:600].cpu().numpy(), 20, depth, seed=81, step_index=k, game_id_base=7 * k)
+            assert np.array_equal(a[:600].cpu().numpy(), oa) and np.array_equal(e[:600].cpu().numpy(), oe)
+        k += 1
+    # the C-ABI itself: sizes, argument checks, and a caller that breaks the contract (jumps in call_index, never clears the buffer)
+    n = 4096
+    need = int(L.lib().g2048_beam_history_bytes(n))
+    assert need == 116992 and int(L.lib().g2048_beam_history_bytes(100)) == 0
+    hist = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    roots = batch(n, 99)
+    ref = ops.beam_get_action(roots, 20, 30, seed=5, step_index=1, want_expanded=True, balanced_order=False)
+    a = torch.empty(n, dtype=torch.uint8, device=DEV); p = torch.empty(n, dtype=torch.float32, device=DEV)
+    e = torch.empty(n, dtype=torch.int32, device=DEV)
+    def call(idx, buf=hist, nbytes=need):
+        L.call(roots.device, L.lib().g2048_beam_get_action_hist, roots.data_ptr(), None, a.data_ptr(), p.data_ptr(), e.data_ptr(), 20, 30,
+               512, 1024, L.u64(5), L.u64(1), L.u64(0), n, 0, buf.data_ptr(), nbytes, idx, L.stream_ptr(roots.device))
+        assert torch.equal(a, ref[0]) and torch.equal(p, ref[1]) and torch.equal(e, ref[2]), idx
+    for idx in (1, 2, 3, 4, 9, 10, 11, 3, 4, 5, 1000000, 1000001, 7, 7, 7, 8):
+        call(idx)
+    with pytest.raises(RuntimeError, match="history"):
+        call(1, nbytes=need - 4)
+    with pytest.raises(RuntimeError, match="history"):
+        call(0)
