@@ -933,7 +933,7 @@ __global__ __launch_bounds__(1024) void beam_order_kernel(const uint4 *__restric
 // lines that rotate (this call counts in one, reads the previous one, clears the next); two sets of lists.
 constexpr uint32_t kHistMagic = 0x32303438u, kHistLine = 32u, kHistSubs = 16u, kHistHdr = kHistLine;
 constexpr uint32_t kHistCnt = 2u * kHistLine, kHistSet = 3u * kHistSubs * kHistLine, kHistLists = kHistCnt + 3u * kHistSet;
-__host__ __device__ constexpr uint32_t hist_seg(uint32_t n) { return (n + kHistSubs - 1u) / kHistSubs; }
+__host__ __device__ constexpr uint32_t hist_seg(uint32_t n) { return (n + kHistSubs - 1u) >> 4; }
 constexpr size_t hist_words(size_t n) { return kHistLists + 2u * 3u * kHistSubs * (size_t)hist_seg((uint32_t)n); }
 
 __device__ __forceinline__ size_t hist_lookup(const uint32_t *hist, uint32_t call_index, uint32_t n, int depth, uint32_t row_len,
@@ -946,12 +946,9 @@ __device__ __forceinline__ size_t hist_lookup(const uint32_t *hist, uint32_t cal
     // lane 16 c + s holds the tickets given out by counter s of class c; inclusive sums along each row of 16 lanes
     uint32_t v = lane < 3u * kHistSubs ? cp[lane * kHistLine] : 0u;
     v = v > n ? n + 1u : v;                                                           // (garbage cannot wrap the sums)
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < (int)kHistSubs; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, (int)kHistSubs);
-        if ((lane & (kHistSubs - 1u)) >= (uint32_t)d) incl += up;
-    }
+    uint32_t incl = v;                                                                // (row_shr shifts zeros in at a row's start)
+    incl += dpp_of<0x111>(incl); incl += dpp_of<0x112>(incl); incl += dpp_of<0x114>(incl); incl += dpp_of<0x118>(incl);
+    static_assert(kHistSubs == 16u, "one DPP row per class");
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), c1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
     const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
     if (magic != kHistMagic || hn != n || hc != call_index - 1u || c0 > n || c1 > n || c2 > n || c0 + c1 + c2 != n) return b;
@@ -962,7 +959,10 @@ __device__ __forceinline__ size_t hist_lookup(const uint32_t *hist, uint32_t cal
     const uint32_t start0 = (r1 < r0 ? c1 : 0u) + (r2 < r0 ? c2 : 0u), start1 = (r0 < r1 ? c0 : 0u) + (r2 < r1 ? c2 : 0u);
     const uint32_t start2 = (r0 < r2 ? c0 : 0u) + (r1 < r2 ? c1 : 0u);
     // block b sits in row b / row_len of the deal; odd rows run backwards
-    const uint32_t rows = (n + row_len - 1u) / row_len, row = b / row_len, q1 = b - row * row_len;
+    const bool pow2 = (row_len & (row_len - 1u)) == 0u;                                // (4 x CUs: a shift on every current part)
+    const uint32_t sh = 31u - (uint32_t)__builtin_clz(row_len | 1u);
+    const uint32_t rows = pow2 ? (n + row_len - 1u) >> sh : (n + row_len - 1u) / row_len, row = pow2 ? b >> sh : b / row_len;
+    const uint32_t q1 = b - row * row_len;
     const uint32_t len = row + 1u == rows ? n - row * row_len : row_len;
     const uint32_t r = row * row_len + ((row & 1u) ? len - 1u - q1 : q1);
     uint32_t cls, idx;
@@ -1010,18 +1010,28 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     }
     if (hist && blockIdx.x == 0 && threadIdx.x < 3u * kHistSubs)     // the counters the call after the next one will count in
         hist[kHistCnt + ((call_index + 1u) % 3u) * kHistSet + threadIdx.x * kHistLine] = 0u;
+    // what the end of the block needs of all this waits in LDS, not in scalar registers that would be spilled inside the level loop
+    __shared__ unsigned long long s_hist_ptr[2];
+    __shared__ uint32_t s_hist[4];
+    if (hist && threadIdx.x == 0) {
+        const uint32_t seg = hist_seg(n);
+        const size_t at = kHistLists + ((size_t)(call_index & 1u) * 3u * kHistSubs + hist_cls * kHistSubs + (blockIdx.x & (kHistSubs - 1u))) * seg;
+        s_hist_ptr[0] = (unsigned long long)(uintptr_t)(hist + at);
+        s_hist_ptr[1] = (unsigned long long)(uintptr_t)(hist + (call_index & 1u) * kHistHdr);
+        s_hist[0] = blockIdx.x == 0 ? 1u : 0u; s_hist[1] = seg; s_hist[2] = call_index; s_hist[3] = n;
+    }
+    const bool with_hist = hist != nullptr;
+    asm volatile("" ::: "memory");
 #ifdef G2048_BEAM_TIMING
     const unsigned long long tick0 = wall_clock64();                // tools/beam_timeline.py: when and where each search ran
 #endif
     const Decision d = beam_decide<PASSES>(sh, root, mask_arg, width, depth, early_thr, mid_thr, k0, k1, id_base + g, flags);
-    if (hist && threadIdx.x == 0) {
-        const uint32_t seg = hist_seg(n);
-        if (hist_idx < seg)
-            hist[kHistLists + ((size_t)(call_index & 1u) * 3u * kHistSubs + hist_cls * kHistSubs + (blockIdx.x & (kHistSubs - 1u))) * seg +
-                 hist_idx] = (uint32_t)g;
-        if (blockIdx.x == 0) {                                       // (only read by the next call, i.e. after this kernel)
-            uint32_t *h = hist + (call_index & 1u) * kHistHdr;
-            h[0] = kHistMagic; h[1] = n; h[2] = call_index;
+    if (with_hist && threadIdx.x == 0) {
+        const uint32_t seg = s_hist[1];
+        if (hist_idx < seg) reinterpret_cast<uint32_t *>((uintptr_t)s_hist_ptr[0])[hist_idx] = (uint32_t)g;
+        if (s_hist[0]) {                                             // block 0 (only read by the next call, i.e. after this kernel)
+            uint32_t *h = reinterpret_cast<uint32_t *>((uintptr_t)s_hist_ptr[1]);
+            h[0] = kHistMagic; h[1] = s_hist[3]; h[2] = s_hist[2];
         }
     }
     if (threadIdx.x == 0) {
