@@ -1152,11 +1152,12 @@ constexpr uint32_t kNone = 0xffffffffu;
 struct SpecSlot {                 // 64 bytes per (game, slot), in the workspace g2048_play_games allocates
     uint32_t board[4], t;         // request: search this root with the draws of move t ...
     uint32_t seq;                 // ... request number (the owner's round), stored last (release); kNone: the game is over
+    unsigned long long res;       // the helper's answer in ONE word: request number << 32 | children generated << 2 | action -- one store,
+                                  // one load per poll (three words before: a second round trip for every result an owner took)
     uint32_t bound;               // a helper serves this slot
-    uint32_t res_action, res_expanded;
-    uint32_t res_seq;             // stored last by the helper: the result answers request res_seq
-    uint32_t pad[6];
+    uint32_t pad[7];
 };
+static_assert(sizeof(SpecSlot) == 64 && offsetof(SpecSlot, res) % 8 == 0, "one slot per 64-byte line, the result word aligned");
 struct SpecCtl { uint32_t resolved, registered, next_unit, started; };     // started: owner blocks that have begun
 
 __device__ __forceinline__ uint32_t ld_acquire(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1200,11 +1201,9 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
             const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)t);
             const Decision d = beam_decide<PASSES>(sh, root, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, id_base + g,
                                                    flags);
-            if (threadIdx.x == 0) {
-                st_relaxed(&slot->res_action, d.action);
-                st_relaxed(&slot->res_expanded, d.expanded);
-                st_release(&slot->res_seq, q);
-            }
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&slot->res, ((unsigned long long)q << 32) | ((unsigned long long)d.expanded << 2) | (d.action & 3u),
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             last = q;
         }
     }
@@ -1297,6 +1296,9 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             if (registered) ++tm_searches;
 #endif
         }
+        // every slot's answer word, fetched once for the round (lane k: slot k); a slot whose answer had not arrived yet is polled again below
+        unsigned long long res_v = 0ull;
+        if (on && lane < (uint32_t)kSpec) res_v = __hip_atomic_load(&my[lane].res, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         while (on && st.alive && st.t < max_moves) {                 // decisions the helpers have made for where we are now
             const uint4 q = s_req_board[lane & (kSpec - 1)];
             const bool hit = lane < (uint32_t)kSpec && ((on >> lane) & 1u) && s_req_t[lane & (kSpec - 1)] == (uint32_t)st.t &&
@@ -1305,13 +1307,20 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             if (!hb) break;
             const uint32_t k = (uint32_t)__builtin_ctzll(hb);
             const unsigned long long t0 = wall_clock64();
-            bool ready;
-            while (!(ready = uniform(ld_acquire(&my[k].res_seq)) == seq) && wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
+            uint32_t r_lo = (uint32_t)__shfl((int)(uint32_t)res_v, (int)k, 64), r_hi = (uint32_t)__shfl((int)(uint32_t)(res_v >> 32), (int)k, 64);
+            r_lo = uniform(r_lo); r_hi = uniform(r_hi);
+            bool ready = r_hi == seq;
+            while (!ready && wall_clock64() - t0 < wait_ticks) {
+                __builtin_amdgcn_s_sleep(8);
+                const unsigned long long r = __hip_atomic_load(&my[k].res, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                r_lo = uniform((uint32_t)r); r_hi = uniform((uint32_t)(r >> 32));
+                ready = r_hi == seq;
+            }
 #ifdef G2048_PLAY_TIMING
             if (!ready) ++tm_late; else ++tm_hits;
 #endif
             if (!ready) break;                                       // a late helper: search this move ourselves
-            const uint32_t action = uniform(ld_relaxed(&my[k].res_action)), ex = uniform(ld_relaxed(&my[k].res_expanded));
+            const uint32_t action = r_lo & 3u, ex = r_lo >> 2;
             const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
             const StepOut o = step_board(st.b, action, rng_draw(k2.k0, k2.k1, gid, 0u));
             game_apply(st, o, ex);
