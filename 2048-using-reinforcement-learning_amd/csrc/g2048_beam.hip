@@ -1134,6 +1134,9 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // Left to the compiler (102 vector registers, four wavefronts per SIMD at width 20): with five or six per SIMD the helper
 // wavefronts are resident from the start and their speculation competes with 4096 running games -- 0.22 s / 0.25 s against
 // 0.20 s (profiles/r03_beam_priority.txt, section 8).
+#ifndef G2048_HELPER_POLL_SLEEP
+#define G2048_HELPER_POLL_SLEEP 16      // x 64 cycles between two looks of a helper at its slot (A/B: 4, 8, 32)
+#endif
 #ifndef G2048_PLAY_DYN_LDS
 #define G2048_PLAY_DYN_LDS 0
 #endif
@@ -1193,7 +1196,7 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
         for (;;) {
             const uint32_t q = uniform(ld_acquire(&slot->seq));
             if (q == kNone) break;                                   // every owner closes its slots when its game ends
-            if (q == last) { __builtin_amdgcn_s_sleep(16); continue; }
+            if (q == last) { __builtin_amdgcn_s_sleep(G2048_HELPER_POLL_SLEEP); continue; }
             const Board root = {{uniform(ld_relaxed(&slot->board[0])), uniform(ld_relaxed(&slot->board[1])),
                                  uniform(ld_relaxed(&slot->board[2])), uniform(ld_relaxed(&slot->board[3]))}};
             const uint32_t t = uniform(ld_relaxed(&slot->t));
