@@ -16,6 +16,7 @@
 
 #include "../../include/g2048.h"
 #include "g2048_board.h"
+#include "g2048_instrument.h"
 #include "g2048_rng.h"
 
 using namespace g2048;
@@ -37,29 +38,19 @@ constexpr int kSimdsPerCu = 4, kFallbackCus = 256;     // CDNA: four SIMDs per c
 // Set by g2048_beam_get_action when every block of the launch is resident at once; with more blocks than the chip holds,
 // wavefronts that end together leave the rest of the grid to a burst dispatch on an emptied chip (8192 games: -10 %).
 constexpr uint32_t kFlagPrioByRemaining = 4u;
-#ifndef G2048_PRIO_T1
-#define G2048_PRIO_T1 2
-#define G2048_PRIO_T2 5
-#define G2048_PRIO_T3 10
-#endif
-constexpr int kPrioT1 = G2048_PRIO_T1, kPrioT2 = G2048_PRIO_T2, kPrioT3 = G2048_PRIO_T3;
+constexpr int kPrioT1 = 2, kPrioT2 = 5, kPrioT3 = 10;     // s_setprio 1 / 2 / 3 above this many remaining levels (any set that separates the last ~10 measures the same)
 struct LaunchPlan { uint32_t order_row, order_min, helper_cap; };
+constexpr uint32_t kHelperDiv = 4u;      // helpers take at most 1 / kHelperDiv of the resident wavefronts (1/2 and 1/1 measured slower)
 constexpr LaunchPlan launch_plan(int cus, int resident_blocks_per_cu)
 {
     const uint32_t c = cus > 0 ? (uint32_t)cus : (uint32_t)kFallbackCus;
     const uint32_t b = resident_blocks_per_cu > 0 ? (uint32_t)resident_blocks_per_cu : 32u;
-#ifndef G2048_HELPER_DIV
-#define G2048_HELPER_DIV 4u
-#endif
-    return LaunchPlan{c * kSimdsPerCu, 4u * c * kSimdsPerCu, c * b / G2048_HELPER_DIV > 0u ? c * b / G2048_HELPER_DIV : 1u};
+    return LaunchPlan{c * kSimdsPerCu, 4u * c * kSimdsPerCu, c * b / kHelperDiv > 0u ? c * b / kHelperDiv : 1u};
 }
 static_assert(launch_plan(256, 32).order_row == 1024 && launch_plan(256, 32).order_min == 4096 &&
-              launch_plan(256, 32).helper_cap == 8192u / G2048_HELPER_DIV, "MI355X: the values rounds 1-2 had hard-coded");
+              launch_plan(256, 32).helper_cap == 8192u / kHelperDiv, "MI355X: the values rounds 1-2 had hard-coded");
 
-#ifndef G2048_SPEC_SLOTS
-#define G2048_SPEC_SLOTS 8
-#endif
-constexpr uint32_t kSpecSlotsPerGame = G2048_SPEC_SLOTS;       // = kSpec below (a power of two)
+constexpr uint32_t kSpecSlotsPerGame = 8u;       // = kSpec below (a power of two; 4 and 16 measured slower, profiles/r03_eval_helpers.txt)
 constexpr uint32_t default_helpers(uint32_t n_games, uint32_t helper_cap)
 {
     const uint32_t want = n_games / 2u > 1024u ? n_games / 2u : 1024u;      // round 3: half the games (a quarter before)
@@ -112,20 +103,6 @@ __device__ __forceinline__ uint32_t pick_by_mask(uint32_t if0, uint32_t if1, uin
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_of(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 
-// One compare-exchange step in two vector instructions (round 3; three to five before: v_max_dpp + v_min_dpp + v_cndmask): the
-// compare reads the partner's key through its DPP operand, the scalar unit turns "partner > mine" into "keep mine" with the
-// step's keep-the-larger lane mask, and the select reads the partner's key through DPP again:
-//     vcc = borrow of dpp(key) - key  (= mine > partner's) ;  vcc ^= ~keep_max ;  key = vcc ? key : dpp(key)
-// gfx950 has no DPP form of v_cmp (VOPC), so the compare is the carry-out of a VOP2 subtraction whose difference is thrown
-// away. The instructions are written out because the select must be the VOP2 form to take a DPP operand; the s_nop covers the
-// "VALU writes a VGPR, a DPP operand reads it" wait states for whatever produced `key` just before.
-#define G2048_CX_DPP(CTRL)                                                                             \
-    asm("s_nop 1\n\t"                                                                                  \
-        "v_sub_co_u32_dpp %0, vcc, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
-        "s_xor_b64 vcc, vcc, %2\n\t"                                                                    \
-        "v_cndmask_b32_dpp %0, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                         \
-        : "=&v"(out) : "v"(src), "s"(~keep_max) : "vcc")
-
 // A keep-the-larger mask that is a union of whole 16-lane rows, or of whole 4-lane banks with the
 // same banks in every row, can be applied by the DPP row_mask / bank_mask of the v_max that follows an unconditional v_min -- no
 // v_cndmask and no 64-bit mask in SGPRs (two s_mov per step otherwise): -1 if the mask is not of that shape.
@@ -154,78 +131,52 @@ constexpr int banks_of_mask(uint64_t m)
     return all == m ? b : -1;
 }
 
+// One compare-exchange step of the 32-bit network. The asm forms are only instantiated for masks of the shape their DPP
+// row_mask / bank_mask immediates can express (if constexpr: an untaken form is never emitted, whatever the optimisation level).
+// (A two-instruction form -- borrow of a DPP subtraction, s_xor with the mask, VOP2 DPP select -- measured 2.7 % slower at 4096
+// games: it lengthens the dependent chain; profiles/r03_beam_latency.txt. Git history has it.)
 template <uint64_t KEEP_MAX, int J>
 __device__ __forceinline__ uint32_t cx_step_m(uint32_t key)
 {
     constexpr uint64_t keep_max = KEEP_MAX;
-#ifndef G2048_BEAM_NO_DPP_MASKS
-    if (J >= 16 && rows_of_mask(KEEP_MAX) > 0) {           // lane swaps: both lanes of a pair hold both keys; the larger on the rows of the mask
+    constexpr int rows = rows_of_mask(KEEP_MAX), banks = banks_of_mask(KEEP_MAX);
+    if constexpr (J >= 16 && rows > 0) {         // lane swaps: both lanes of a pair hold both keys; the larger on the rows of the mask
         uint32_t a, b, out;
         asm("s_nop 1" : "+v"(key));              // (a written-out step may have produced key: wait states before the lane swap reads it)
-        if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); a = r[0]; b = r[1]; }
+        if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); a = r[0]; b = r[1]; }
         else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); a = r[0]; b = r[1]; }
         asm("v_min_u32 %0, %1, %2\n\t"
             "s_nop 0\n\t"                                   // (with the v_min: the wait states between the swap's write and the DPP read)
             "v_max_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf"
-            : "=&v"(out) : "v"(a), "v"(b), "i"(rows_of_mask(KEEP_MAX)));
+            : "=&v"(out) : "v"(a), "v"(b), "i"(rows));
         return out;
-    }
-    if (J == 8 && banks_of_mask(KEEP_MAX) > 0) {
+    } else if constexpr (J == 8 && banks > 0) {
         uint32_t out;
         asm("s_nop 1\n\t"
             "v_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:%2"
-            : "=&v"(out) : "v"(key), "i"(banks_of_mask(KEEP_MAX)));
+            : "=&v"(out) : "v"(key), "i"(banks));
         return out;
-    }
-    if (J == 4 && banks_of_mask(KEEP_MAX) > 0) {           // e ^ 3 (quad_perm [3,2,1,0]) into a scratch register, e ^ 7 on the operand = e ^ 4
+    } else if constexpr (J == 4 && banks > 0) {  // e ^ 3 (quad_perm [3,2,1,0]) into a scratch register, e ^ 7 on the operand = e ^ 4
         uint32_t out, tmp;
         asm("s_nop 1\n\t"
             "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
             "s_nop 1\n\t"
             "v_min_u32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
             "v_max_u32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:%3"
-            : "=&v"(out), "=&v"(tmp) : "v"(key), "i"(banks_of_mask(KEEP_MAX)));
+            : "=&v"(out), "=&v"(tmp) : "v"(key), "i"(banks));
         return out;
-    }
-#endif
-#ifndef G2048_BEAM_CX_SUBCO          // default: v_max_dpp + v_min_dpp + v_cndmask (A/B switch: the two-instruction form below)
-    {
+    } else {                                     // v_max_dpp + v_min_dpp + v_cndmask by the step's lane mask
         uint32_t hi, lo;
-        if (J == 1) { hi = max(dpp_of<0xB1>(key), key); lo = min(dpp_of<0xB1>(key), key); }
-        else if (J == 2) { hi = max(dpp_of<0x4E>(key), key); lo = min(dpp_of<0x4E>(key), key); }
-        else if (J == 4) { const uint32_t r = dpp_of<0x1B>(key); hi = max(dpp_of<0x141>(r), key); lo = min(dpp_of<0x141>(r), key); }
-        else if (J == 8) { hi = max(dpp_of<0x128>(key), key); lo = min(dpp_of<0x128>(key), key); }
-        else if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); hi = max(r[0], r[1]); lo = min(r[0], r[1]); }
+        if constexpr (J == 1) { hi = max(dpp_of<0xB1>(key), key); lo = min(dpp_of<0xB1>(key), key); }
+        else if constexpr (J == 2) { hi = max(dpp_of<0x4E>(key), key); lo = min(dpp_of<0x4E>(key), key); }
+        else if constexpr (J == 4) { const uint32_t r = dpp_of<0x1B>(key); hi = max(dpp_of<0x141>(r), key); lo = min(dpp_of<0x141>(r), key); }
+        else if constexpr (J == 8) { hi = max(dpp_of<0x128>(key), key); lo = min(dpp_of<0x128>(key), key); }
+        else if constexpr (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); hi = max(r[0], r[1]); lo = min(r[0], r[1]); }
         else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); hi = max(r[0], r[1]); lo = min(r[0], r[1]); }
         return pick_by_mask(lo, hi, keep_max);
     }
-#endif
-    if (J == 16 || J == 32) {                    // odd rows of one copy <-> even rows of the other: both lanes of a pair see both keys
-        uint32_t a, b;
-        asm("s_nop 1" : "+v"(key));              // (a written-out step may have produced key: wait states before the lane swap reads it)
-        if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(key, key, false, false); a = r[0]; b = r[1]; }
-        else { const auto r = __builtin_amdgcn_permlane32_swap(key, key, false, false); a = r[0]; b = r[1]; }
-        return pick_by_mask(b, a, ~(__ballot(a > b) ^ keep_max));       // the larger one where keep_max, else the smaller
-    }
-    uint32_t out, src = key;
-    if (J == 1) G2048_CX_DPP("quad_perm:[1,0,3,2]");
-    else if (J == 2) G2048_CX_DPP("quad_perm:[2,3,0,1]");
-    else if (J == 8) G2048_CX_DPP("row_ror:8");
-    else {
-        // J == 4: e ^ 3 (quad_perm [3,2,1,0]) into a scratch register, then e ^ 7 (row_half_mirror) on the operands = e ^ 4
-        uint32_t tmp;
-        asm("s_nop 1\n\t"
-            "v_mov_b32_dpp %1, %2 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_sub_co_u32_dpp %0, vcc, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "s_xor_b64 vcc, vcc, %3\n\t"
-            "v_cndmask_b32_dpp %0, %1, %2, vcc row_half_mirror row_mask:0xf bank_mask:0xf"
-            : "=&v"(out), "=&v"(tmp) : "v"(src), "s"(~keep_max) : "vcc");
-    }
-    return out;
 }
-#undef G2048_CX_DPP
 
 template <int K, int J>
 __device__ __forceinline__ uint32_t cx_step(uint32_t key) { return cx_step_m<cx_mask(K, J), J>(key); }
@@ -276,26 +227,6 @@ __device__ __forceinline__ uint32_t top64_desc(uint32_t a, uint32_t b, bool with
     a = cx_step<32, 16>(a); a = cx_step<32, 8>(a); a = cx_step<32, 4>(a); a = cx_step<32, 2>(a); a = cx_step<32, 1>(a);
     a = merge64_desc(a);
     return merge64_desc(pick_by_mask(a, b, 0xffff000000000000ull));
-}
-
-// The 32 largest of up to 128 keys held in two registers (a lane's two children in the lane-resident search below),
-// descending in lanes 0..31. The first ten stages sort all four 32-lane quarter sets at once -- a: lower half descending,
-// upper half ascending (the standard k <= 32 stages); b: the same stages with every direction inverted --, so max(a, b)
-// holds, in each half, the 32 largest of that half's two quarter sets as a bitonic sequence; five merge steps sort the halves
-// (lower descending, upper ascending), six more sort the whole. 26 step latencies, the two registers' steps independent of
-// each other (round 2's 64 + 16 arrangement: 37 steps in one dependent chain).
-__device__ __forceinline__ uint32_t top32_of_pair(uint32_t a, uint32_t b)
-{
-#define G2048_STEP2(K, J) a = cx_step_m<cx_mask(K, J), J>(a); b = cx_step_m<~cx_mask(K, J), J>(b);
-    G2048_STEP2(2, 1)
-    G2048_STEP2(4, 2) G2048_STEP2(4, 1)
-    G2048_STEP2(8, 4) G2048_STEP2(8, 2) G2048_STEP2(8, 1)
-    G2048_STEP2(16, 8) G2048_STEP2(16, 4) G2048_STEP2(16, 2) G2048_STEP2(16, 1)
-    G2048_STEP2(32, 16) G2048_STEP2(32, 8) G2048_STEP2(32, 4) G2048_STEP2(32, 2) G2048_STEP2(32, 1)
-#undef G2048_STEP2
-    uint32_t t = max(a, b);
-    t = cx_step<32, 16>(t); t = cx_step<32, 8>(t); t = cx_step<32, 4>(t); t = cx_step<32, 2>(t); t = cx_step<32, 1>(t);
-    return merge64_desc(t);
 }
 
 // The same network on 64-bit keys (hi, lo) for the levels whose scores are f64 (1..3): the partner's two words come through
@@ -366,11 +297,6 @@ __device__ __forceinline__ Key64 top64_desc64(Key64 a, Key64 b, bool with_b)
 
 __global__ __launch_bounds__(64) void sort_selftest_kernel(uint32_t *keys, const uint32_t *extra, int with_extra, int wide)
 {
-    if (wide == 2) {                             // pair mode: 64 + 64 keys, the 32 largest descending in lanes 0..31
-        const uint32_t a = keys[blockIdx.x * 64 + threadIdx.x], b = extra[blockIdx.x * 64 + threadIdx.x];
-        keys[blockIdx.x * 64 + threadIdx.x] = top32_of_pair(a, b);
-        return;
-    }
     if (wide) {                                  // 64-bit keys: (lo, hi) word pairs
         const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
         const Key64 a = {keys[2 * i + 1], keys[2 * i]};
@@ -403,10 +329,6 @@ struct BeamShared {
 
 struct Decision { uint32_t action; float prob; uint32_t expanded; };
 
-#ifdef G2048_BEAM_LANES
-#include "g2048_beam_lanes.inc"      // A/B only: the lane-resident formulation (bit-exact, measured slower; see the file's header)
-#endif
-
 // BeamSearchAgent.get_action for the game this wavefront owns. mask_in < 0: no caller mask. Every lane returns the same
 // Decision. Must be called by all 64 lanes (it contains workgroup barriers).
 //   stage A: lane 2p + axis makes BOTH moves of one axis of parent p (g2048_board.h move_axis), 32 parents per round; the
@@ -438,13 +360,6 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
     const bool fixed_down = (flags & 1u) != 0u;          // G2048_BEAM_FIXED_DOWN
     const bool count_rank = (flags & 2u) != 0u;          // G2048_BEAM_RANK_BY_COUNTING
     const bool by_remaining = (flags & kFlagPrioByRemaining) != 0u;
-#ifdef G2048_BEAM_LANES
-    // A/B only: the lane-resident formulation above for beams up to 32 wide. Bit-exact (the whole GPU suite passes on it), but
-    // 11.6 % more vector instructions per decision and only 2 % less latency for a lone wavefront: 5.6 % slower at 4096 games,
-    // 7.6 % at 8192 (profiles/r03_beam_latency.txt)
-    if (PASSES <= 2 && !count_rank)
-        return beam_decide_lanes<PASSES>(sh, root, mask_in, width, depth, early_thr, mid_thr, k0, k1, gid, fixed_down);
-#endif
 
     // :82-93 -- caller mask or the agent's own validity; 0 or 1 valid move short-circuit
     const uint32_t mask = mask_in >= 0 ? (uint32_t)(mask_in & 15) : valid_mask_agent(root, fixed_down);
@@ -554,7 +469,6 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
         // ---- stage B: spawn + score of the compacted children, one per lane and pass (a pass only runs if it has children)
         // Ranking by sorting network (above) for beams up to 32 wide, when the level has 17 .. 80 children (wave-uniform): then
         // the up to 16 children beyond the first 64 sit in lanes 48..63 of the second pass, where the network wants their keys.
-#ifndef G2048_BEAM_NO_DUAL
         // The common level of a width-17..32 search: _fast_evaluate scores and 65..80 children. Both passes -- 64 children, then
         // the up to 16 more in lanes 48..63 -- the write-back and the sorting network run as ONE straight-line block, so that the
         // second pass's spawn + score (independent work) fills the issue slots the first pass's dependent chains and the network's
@@ -568,25 +482,6 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             const uint32_t nm0 = count_empty(c0);
             const unsigned long long b0 = __ballot(nm0 != 0u);
             const uint32_t j0 = draws + prefix_count(b0);
-#ifdef G2048_BEAM_TAIL_BOARDS       // A/B: round 2's second pass -- a whole board per lane in lanes 48..63 (147 instructions for <= 16 children)
-            const uint32_t ci1 = lane + 16u;
-            const bool live1 = lane >= 48u && ci1 < total_valid;
-            const uint4 cv1 = s_cboard[live1 ? ci1 : 0u];
-            const uint32_t cr1 = s_croot[live1 ? ci1 : 0u];
-            Board c1 = {{cv1.x, cv1.y, cv1.z, cv1.w}};
-            const uint32_t nm1 = count_empty(c1);
-            const unsigned long long b1 = __ballot(live1 && nm1 != 0u);
-            const uint32_t j1 = draws + (uint32_t)__popcll(b0) + prefix_count(b1);
-            spawn(c1, rng_draw(k0, k1, gid, j1));
-            const uint32_t pm1 = cr1 >> 8;
-            const uint32_t cm1 = pm1 + (has_code(c1, pm1 + 1u) ? 1u : 0u);
-            const uint32_t e1 = (eval_fast_u32_known(c1, nm1 - (nm1 ? 1u : 0u), cm1) << 9) + (511u - ci1);
-            const uint32_t key1 = live1 ? e1 : 0u;
-            if (live1) {
-                s_cboard[ci1] = make_uint4(c1.w[0], c1.w[1], c1.w[2], c1.w[3]);
-                s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
-            }
-#else
             // second stream: children 64..79, one ROW per lane -- lane 4k + r holds row r of child 64 + k, so the 16 children
             // fill the wavefront instead of a quarter of it; what spans the board (empty count, rank of the spawn cell, max
             // code, corners, vertical neighbours) moves between the four lanes of a quad through DPP quad permutes. 84 vector
@@ -626,14 +521,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 reinterpret_cast<uint32_t *>(s_cboard)[256u + lane] = w1;
                 if (tq.last) s_croot[ci1] = (cr1 & 0xffu) | (cm1 << 8);
             }
-#endif
-#ifdef G2048_BEAM_SPAWN_PREFIX          // A/B switches: the three spawn formulations of g2048_board.h (all exact; profiles/r03_beam_latency.txt)
-            spawn_prefix(c0, rng_draw(k0, k1, gid, j0));
-#elif defined(G2048_BEAM_SPAWN_SELECT)
-            spawn(c0, rng_draw(k0, k1, gid, j0));
-#else
             spawn_rowprefix(c0, rng_draw(k0, k1, gid, j0));                      // :155 (a no-op on a full board)
-#endif
             draws += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
             const uint32_t pm0 = cr0 >> 8;
             const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
@@ -642,39 +530,18 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             s_croot[lane] = (cr0 & 0xffu) | (cm0 << 8);
             pick = 511u - (top64_desc(key0, key1, true) & 511u);
             nb = width;                                                          // more than 64 children, width <= 32
-#ifdef G2048_BEAM_COPY_BEAM             // A/B: round 2's hand-over through the beam array
-            __syncthreads();
-            if ((int)lane < nb) {
-                s_board[lane] = s_cboard[pick];
-                s_root[lane] = s_croot[pick];
-            }
-            __syncthreads();
-#else
             from_pick = true;
-#endif
             continue;
         }
-#endif
-#ifndef G2048_BEAM_NO_SINGLE
         // the same for a fast level with up to 64 children (level 0 included): one stream, the 64-key network, hand-over by slots
-#ifdef G2048_BEAM_SINGLE_FROM_17
-        if (PASSES <= 2 && fast && !count_rank && total_valid > 16u && total_valid <= 64u) {
-#else
         if (PASSES <= 2 && fast && !count_rank && total_valid <= 64u) {
-#endif
             const bool live0 = lane < total_valid;
             const uint4 cv0 = s_cboard[live0 ? lane : 0u];
             const uint32_t cr0 = s_croot[live0 ? lane : 0u];
             Board c0 = {{cv0.x, cv0.y, cv0.z, cv0.w}};
             const uint32_t nm0 = count_empty(c0);
             const unsigned long long b0 = __ballot(live0 && nm0 != 0u);
-#ifdef G2048_BEAM_SPAWN_PREFIX
-            spawn_prefix(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));
-#elif defined(G2048_BEAM_SPAWN_SELECT)
-            spawn(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));
-#else
             spawn_rowprefix(c0, rng_draw(k0, k1, gid, draws + prefix_count(b0)));    // :155 (a no-op on a full board)
-#endif
             draws += (uint32_t)__popcll(b0);
             const uint32_t pm0 = cr0 >> 8;
             const uint32_t cm0 = pm0 + (has_code(c0, pm0 + 1u) ? 1u : 0u);
@@ -688,7 +555,6 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
             from_pick = true;
             continue;
         }
-#endif
         from_pick = false;
         const bool net = PASSES <= 2 && total_valid > 16u && total_valid <= (PASSES == 2 ? 80u : 64u) && !(count_rank && fast);
         Board child[PASSES];
@@ -715,13 +581,9 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 const unsigned long long bc = __ballot(live && n_moved != 0u);
                 const uint32_t j = draws + prefix_count(bc);
                 draws += (uint32_t)__popcll(bc);
-#ifdef G2048_BEAM_SPAWN_PREFIX      // A/B (round 3: 2.7 % slower at 4096 games although it is 50 issue cycles cheaper per pass)
-                spawn_prefix(c, rng_draw(k0, k1, gid, j));
-#elif defined(G2048_BEAM_SPAWN_SELECT)
-                spawn(c, rng_draw(k0, k1, gid, j));
-#else
+                // (row select + byte-wise prefix inside the row; the all-rows prefix form is 50 issue cycles cheaper per pass and
+                // measured 2.7 % slower at 4096 games -- a longer dependent chain; profiles/r03_beam_latency.txt)
                 spawn_rowprefix(c, rng_draw(k0, k1, gid, j));                    // :118 / :155; a no-op on a full board
-#endif
                 // :122 / :158-161. What the evaluators need is already known: the empty count (one fewer after a spawn)
                 // and the max code -- a move raises the parent's max by at most one, exactly when some cell now holds
                 // parent max + 1 (two max tiles merged, or a 2/4 spawned onto a board whose max was lower)
@@ -782,16 +644,7 @@ __device__ __forceinline__ Decision beam_decide(BeamShared<PASSES> &sh, const Bo
                 }
             }
             if (exact) {
-#ifdef G2048_BEAM_COPY_BEAM
-                __syncthreads();
-                if ((int)lane < nb) {
-                    s_board[lane] = s_cboard[pick];
-                    s_root[lane] = s_croot[pick];
-                }
-                __syncthreads();
-#else
                 from_pick = true;
-#endif
                 continue;
             }
         }
@@ -1022,9 +875,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     }
     const bool with_hist = hist != nullptr;
     asm volatile("" ::: "memory");
-#ifdef G2048_BEAM_TIMING
-    const unsigned long long tick0 = wall_clock64();                // tools/beam_timeline.py: when and where each search ran
-#endif
+    [[maybe_unused]] const unsigned long long tick0 = kBeamTiming ? wall_clock64() : 0ull;       // (measurement builds only: when and where each search ran)
     const Decision d = beam_decide<PASSES>(sh, root, mask_arg, width, depth, early_thr, mid_thr, k0, k1, id_base + g, flags);
     if (with_hist && threadIdx.x == 0) {
         const uint32_t seg = s_hist[1];
@@ -1036,17 +887,14 @@ __global__ __launch_bounds__(64) void beam_kernel(const uint4 *__restrict__ root
     }
     if (threadIdx.x == 0) {
         action_out[g] = (uint8_t)d.action;
-#ifdef G2048_BEAM_TIMING
-        const uint32_t h = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-        // HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]  ->  13-bit SIMD number
-        const uint32_t simd = ((h >> 4) & 3u) | (((h >> 8) & 15u) << 2) | (((h >> 12) & 1u) << 6) | (((h >> 13) & 7u) << 7) | ((x & 15u) << 10);
-        const uint32_t dur = (uint32_t)(wall_clock64() - tick0);
-        prob_out[g] = __uint_as_float((uint32_t)tick0);
-        if (expanded_out) expanded_out[g] = (dur < 0x3ffffu ? dur : 0x3ffffu) | (simd << 18);
-#else
-        prob_out[g] = d.prob;
-        if (expanded_out) expanded_out[g] = d.expanded;
-#endif
+        if constexpr (kBeamTiming) {
+            const uint32_t dur = (uint32_t)(wall_clock64() - tick0);
+            prob_out[g] = __uint_as_float((uint32_t)tick0);
+            if (expanded_out) expanded_out[g] = (dur < 0x3ffffu ? dur : 0x3ffffu) | (simd_id() << 18);
+        } else {
+            prob_out[g] = d.prob;
+            if (expanded_out) expanded_out[g] = d.expanded;
+        }
     }
 }
 
@@ -1070,8 +918,11 @@ struct GameState {
     bool alive;
 };
 
-__device__ __forceinline__ void game_apply(GameState &st, const StepOut &o, uint32_t expanded)
+// actions: this game's row of the caller's action stream (one byte per move, written as the move is applied -- by the owner,
+// whoever searched it), or nullptr
+__device__ __forceinline__ void game_apply(GameState &st, const StepOut &o, uint32_t expanded, uint32_t action, uint8_t *actions)
 {
+    if (actions && threadIdx.x == 0) actions[st.t] = (uint8_t)action;
     st.b = o.board;
     st.sc += o.gain;
     st.expanded += expanded;
@@ -1103,17 +954,18 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
                                                  int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
                                                  unsigned long long *__restrict__ expanded_out, uint8_t *__restrict__ alive_out,
                                                  int width, int depth, uint32_t early_thr, uint32_t mid_thr, int max_moves,
-                                                 uint64_t seed, uint64_t id_base, uint32_t flags)
+                                                 uint64_t seed, uint64_t id_base, uint32_t flags, uint8_t *__restrict__ actions_out)
 {
     __shared__ BeamShared<PASSES> sh;
     const size_t g = blockIdx.x;
     const uint64_t gid = id_base + g;
+    uint8_t *const my_actions = actions_out ? actions_out + g * (size_t)max_moves : nullptr;
     const uint4 rv = boards[g];
     GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     while (st.t < max_moves && st.alive) {
         const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t), ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
-        game_apply(st, step_board(st.b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u)), d.expanded);
+        game_apply(st, step_board(st.b, d.action, rng_draw(ks.k0, ks.k1, gid, 0u)), d.expanded, d.action, my_actions);
     }
     if (threadIdx.x == 0) game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
 }
@@ -1130,24 +982,11 @@ __global__ __launch_bounds__(64) void play_kernel(uint4 *__restrict__ boards, ui
 // searching again, and so on down the chain. A helper's decision is beam_decide on exactly the root and draws the owner
 // would have used, so the games are the same with or without helpers (tests/test_gpu_evaluate.py); only the time changes.
 // Owners never wait for helpers beyond a bounded poll of a posted result, helpers leave when every game is resolved.
-// A/B: an occupancy request for the evaluation kernel, e.g. -D'G2048_PLAY_SPEC_WAVES=__attribute__((amdgpu_waves_per_eu(5,8)))'.
-// Left to the compiler (102 vector registers, four wavefronts per SIMD at width 20): with five or six per SIMD the helper
-// wavefronts are resident from the start and their speculation competes with 4096 running games -- 0.22 s / 0.25 s against
-// 0.20 s (profiles/r03_beam_priority.txt, section 8).
-#ifndef G2048_HELPER_POLL_SLEEP
-#define G2048_HELPER_POLL_SLEEP 16      // x 64 cycles between two looks of a helper at its slot (A/B: 4, 8, 32)
-#endif
-#ifndef G2048_PLAY_DYN_LDS
-#define G2048_PLAY_DYN_LDS 0
-#endif
-constexpr size_t kPlayDynLds = G2048_PLAY_DYN_LDS;      // unused LDS requested per block: caps the blocks a compute unit holds
-#ifndef G2048_PLAY_SPEC_WAVES
-#define G2048_PLAY_SPEC_WAVES
-#endif
-#ifndef G2048_PLAY_PRIO_OWNER
-#define G2048_PLAY_PRIO_OWNER 3
-#define G2048_PLAY_PRIO_HELPER 3
-#endif
+// Occupancy is left to the compiler: forced to five or six wavefronts per SIMD the helper wavefronts are resident from the
+// start and their speculation competes with 4096 running games -- 0.22 s / 0.25 s against 0.20 s; capping the resident blocks
+// with unused LDS 0.21 - 0.23 s (profiles/r03_beam_priority.txt, section 8).
+constexpr int kHelperPollSleep = 16;     // x 64 cycles between two looks of a helper at its slot (4, 8, 32: no effect measured)
+constexpr int kPrioOwner = 3, kPrioHelper = 3;       // s_setprio of a registered game's owner and of the helpers (ordinary games: 0)
 constexpr int kSpec = (int)kSpecSlotsPerGame;
 constexpr size_t kSpecMaxGames = 1u << 16;           // beyond this the workspace is not worth it: one wavefront per game
 constexpr uint32_t kNone = 0xffffffffu;
@@ -1196,7 +1035,7 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
         for (;;) {
             const uint32_t q = uniform(ld_acquire(&slot->seq));
             if (q == kNone) break;                                   // every owner closes its slots when its game ends
-            if (q == last) { __builtin_amdgcn_s_sleep(G2048_HELPER_POLL_SLEEP); continue; }
+            if (q == last) { __builtin_amdgcn_s_sleep(kHelperPollSleep); continue; }
             const Board root = {{uniform(ld_relaxed(&slot->board[0])), uniform(ld_relaxed(&slot->board[1])),
                                  uniform(ld_relaxed(&slot->board[2])), uniform(ld_relaxed(&slot->board[3]))}};
             const uint32_t t = uniform(ld_relaxed(&slot->t));
@@ -1213,20 +1052,21 @@ __device__ void spec_helper(BeamShared<PASSES> &sh, SpecCtl *ctl, const uint32_t
 }
 
 template <int PASSES>
-__global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
+__global__ __launch_bounds__(64) void play_spec_kernel(uint4 *__restrict__ boards, uint32_t *__restrict__ score,
                                                       int32_t *__restrict__ moves_out, int32_t *__restrict__ valid_out,
                                                       int32_t *__restrict__ invalid_out, int4 *__restrict__ milestone_out,
                                                       unsigned long long *__restrict__ expanded_out,
                                                       uint8_t *__restrict__ alive_out, int width, int depth, uint32_t early_thr,
                                                       uint32_t mid_thr, int max_moves, uint64_t seed, uint64_t id_base,
-                                                      uint32_t flags, SpecCtl *ctl, uint32_t *reg_list, SpecSlot *slots,
-                                                      uint32_t n_games, int stuck_thr, uint32_t reg_resolved, uint32_t wait_ticks)
+                                                      uint32_t flags, uint8_t *__restrict__ actions_out, SpecCtl *ctl, uint32_t *reg_list,
+                                                      SpecSlot *slots, uint32_t n_games, int stuck_thr, uint32_t reg_resolved,
+                                                      uint32_t wait_ticks)
 {
     __shared__ BeamShared<PASSES> sh;
     __shared__ uint4 s_req_board[kSpec];
     __shared__ uint32_t s_req_t[kSpec];
     if (blockIdx.x >= n_games) {
-        __builtin_amdgcn_s_setprio(G2048_PLAY_PRIO_HELPER);
+        __builtin_amdgcn_s_setprio(kPrioHelper);
         spec_helper<PASSES>(sh, ctl, reg_list, slots, n_games, width, depth, early_thr, mid_thr, seed, id_base, flags);
         return;
     }
@@ -1236,12 +1076,12 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
     const uint4 rv = boards[g];
     GameState st = {Board{{rv.x, rv.y, rv.z, rv.w}}, score[g], {-1, -1, -1, -1, -1, -1, -1, -1}, 0, 0, 0, 0ull, true};
     SpecSlot *const my = slots + g * kSpec;
+    uint8_t *const my_actions = actions_out ? actions_out + g * (size_t)max_moves : nullptr;
     if (lane == 0) atomicAdd(&ctl->started, 1u);
-#ifdef G2048_PLAY_TIMING      // tools/play_timeline.py: the milestone record carries when / where the game ran instead
-    const uint32_t tm_start = (uint32_t)wall_clock64();
-    int32_t tm_reg_t = -1, tm_searches = 0, tm_hits = 0, tm_late = 0;
-    uint32_t tm_reg_tick = 0u;
-#endif
+    // (measurement builds only, tools/play_timeline.py: the milestone record then carries when / where the game ran)
+    [[maybe_unused]] const uint32_t tm_start = kPlayTiming ? (uint32_t)wall_clock64() : 0u;
+    [[maybe_unused]] int32_t tm_reg_t = -1, tm_searches = 0, tm_hits = 0, tm_late = 0;
+    [[maybe_unused]] uint32_t tm_reg_tick = 0u;
     bool registered = false;
     uint32_t seq = 0u;
     int stuck = 0;                                                   // invalid moves minus valid ones, floored at 0
@@ -1249,10 +1089,8 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
         if (!registered && (stuck >= stuck_thr || ((st.t & 31) == 0 && uniform(ld_relaxed(&ctl->resolved)) >= reg_resolved))) {
             if (lane == 0) st_release(&reg_list[atomicAdd(&ctl->registered, 1u)], (uint32_t)g);
             registered = true;
-            __builtin_amdgcn_s_setprio(G2048_PLAY_PRIO_OWNER);         // a registered game is on the run's critical path
-#ifdef G2048_PLAY_TIMING
-            tm_reg_t = st.t; tm_reg_tick = (uint32_t)wall_clock64();
-#endif
+            __builtin_amdgcn_s_setprio(kPrioOwner);         // a registered game is on the run's critical path
+            if constexpr (kPlayTiming) { tm_reg_t = st.t; tm_reg_tick = (uint32_t)wall_clock64(); }
         }
         const Keys ks = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
         const uint32_t draw = rng_draw(ks.k0, ks.k1, gid, 0u);
@@ -1293,11 +1131,9 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
             const Keys kb = rng_keys(seed, DOM_BEAM, (uint64_t)st.t);
             const Decision d = beam_decide<PASSES>(sh, st.b, -1, width, depth, early_thr, mid_thr, kb.k0, kb.k1, gid, flags);
             const StepOut o = step_board(st.b, d.action, draw);
-            game_apply(st, o, d.expanded);
+            game_apply(st, o, d.expanded, d.action, my_actions);
             stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
-#ifdef G2048_PLAY_TIMING
-            if (registered) ++tm_searches;
-#endif
+            if constexpr (kPlayTiming) { if (registered) ++tm_searches; }
         }
         // every slot's answer word, fetched once for the round (lane k: slot k); a slot whose answer had not arrived yet is polled again below
         unsigned long long res_v = 0ull;
@@ -1319,14 +1155,12 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
                 r_lo = uniform((uint32_t)r); r_hi = uniform((uint32_t)(r >> 32));
                 ready = r_hi == seq;
             }
-#ifdef G2048_PLAY_TIMING
-            if (!ready) ++tm_late; else ++tm_hits;
-#endif
+            if constexpr (kPlayTiming) { if (!ready) ++tm_late; else ++tm_hits; }
             if (!ready) break;                                       // a late helper: search this move ourselves
             const uint32_t action = r_lo & 3u, ex = r_lo >> 2;
             const Keys k2 = rng_keys(seed, DOM_STEP, (uint64_t)st.t);
             const StepOut o = step_board(st.b, action, rng_draw(k2.k0, k2.k1, gid, 0u));
-            game_apply(st, o, ex);
+            game_apply(st, o, ex, action, my_actions);
             stuck = (o.flags & G2048_FLAG_VALID) ? max(stuck - 1, 0) : stuck + 1;
             on &= ~(1u << k);
         }
@@ -1335,10 +1169,10 @@ __global__ __launch_bounds__(64) G2048_PLAY_SPEC_WAVES void play_spec_kernel(uin
     if (lane < (uint32_t)kSpec) st_release(&my[lane].seq, kNone);
     if (lane == 0) {
         game_store(st, g, boards, score, moves_out, valid_out, invalid_out, milestone_out, expanded_out, alive_out);
-#ifdef G2048_PLAY_TIMING
-        milestone_out[2 * g] = make_int4((int)tm_start, (int)(uint32_t)wall_clock64(), tm_reg_t, (int)tm_reg_tick);
-        milestone_out[2 * g + 1] = make_int4(tm_searches, tm_hits, tm_late, 0);
-#endif
+        if constexpr (kPlayTiming) {
+            milestone_out[2 * g] = make_int4((int)tm_start, (int)(uint32_t)wall_clock64(), tm_reg_t, (int)tm_reg_tick);
+            milestone_out[2 * g + 1] = make_int4(tm_searches, tm_hits, tm_late, 0);
+        }
         atomicAdd(&ctl->resolved, 1u);
     }
 }
@@ -1391,10 +1225,8 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
     const dim3 grid((unsigned)n_games);
     const uint4 *roots = static_cast<const uint4 *>(root_boards);
     uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
-#ifndef G2048_BEAM_NO_PRIO
     // every block resident at once (4096 games on MI355X: four of the six a SIMD holds): issue priority by remaining levels
     if (n_games <= beam_resident_blocks(width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8)) fd |= kFlagPrioByRemaining;
-#endif
     // with scratch for it, and a batch of at least four searches per SIMD, the blocks take the games in a depth-balanced order
     uint32_t *order = nullptr;
     const LaunchPlan plan = launch_plan((order_ws || hist) ? device_cus() : 0, 0);
@@ -1421,11 +1253,10 @@ static int beam_impl(const void *root_boards, const uint8_t *valid_mask_or_null,
 static int play_resident_per_cu(int passes)          // blocks of play_spec_kernel<passes> a compute unit holds (0: could not ask)
 {
     int resident = 0;
-    const size_t dyn = kPlayDynLds;
-    const hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, dyn)
-                        : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, dyn)
-                        : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, dyn)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, dyn);
+    const hipError_t oe = passes == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<1>, 64, 0)
+                        : passes == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<2>, 64, 0)
+                        : passes == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<4>, 64, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, play_spec_kernel<8>, 64, 0);
     if (oe != hipSuccess) { (void)hipGetLastError(); return 0; }
     return resident;
 }
@@ -1439,8 +1270,8 @@ static size_t play_workspace_bytes(size_t n_games)
 // caller_ws: nullptr = allocate the helper workspace from the stream-ordered allocator (g2048_play_games)
 static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
                      int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
-                     int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
-                     uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, void *caller_ws,
+                     uint8_t *actions_out_or_null, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
+                     uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream, void *caller_ws,
                      const uint32_t *tuning = nullptr)
 {
     if (n_games == 0) return G2048_OK;
@@ -1457,9 +1288,13 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t fd = ((opts & G2048_BEAM_FIXED_DOWN) ? 1u : 0u) | ((opts & G2048_BEAM_RANK_BY_COUNTING) ? 2u : 0u);
     const int passes = width <= 16 ? 1 : width <= 32 ? 2 : width <= 64 ? 4 : 8;
+    if (actions_out_or_null && max_moves > 0) {         // 0xFF = "no move": the owners overwrite one byte per move they apply
+        const hipError_t me = hipMemsetAsync(actions_out_or_null, 0xff, n_games * (size_t)max_moves, s);
+        if (me != hipSuccess) { g2048_set_last_error_(hipGetErrorString(me)); return G2048_ERR_HIP; }
+    }
 #define G2048_PLAY_ARGS static_cast<uint4 *>(boards_inout), score_inout, moves_out, valid_out, invalid_out, \
                         reinterpret_cast<int4 *>(milestone_move_out), expanded_sum_out_or_null, alive_out, width, depth, \
-                        (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd
+                        (uint32_t)early_threshold, (uint32_t)mid_threshold, max_moves, seed, game_id_base, fd, actions_out_or_null
     if ((opts & G2048_PLAY_ONE_PHASE) || n_games > kSpecMaxGames) {
         const dim3 grid((unsigned)n_games);
 #define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS)
@@ -1506,7 +1341,7 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
             g2048_set_last_error_(hipGetErrorString(me)); return G2048_ERR_HIP;
         }
         const dim3 grid((unsigned)(n + helpers));
-#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), kPlayDynLds, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
+#define G2048_LAUNCH_PLAY(P) hipLaunchKernelGGL(play_spec_kernel<P>, grid, dim3(64), 0, s, G2048_PLAY_ARGS, ctl, reg_list, slots, n, \
                                                 stuck_thr, reg_resolved, wait_us * 100u)
         if (passes == 1) G2048_LAUNCH_PLAY(1);
         else if (passes == 2) G2048_LAUNCH_PLAY(2);
@@ -1522,12 +1357,12 @@ static int play_impl(void *boards_inout, uint32_t *score_inout, int32_t *moves_o
 }
 
 int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
-                     int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                     int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out, uint8_t *actions_out_or_null,
                      int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
                      uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream)
 {
     return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
-                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     alive_out, actions_out_or_null, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
                      nullptr);
 }
 
@@ -1537,7 +1372,7 @@ size_t g2048_play_games_workspace(size_t n_games)
 }
 
 int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
-                        int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                        int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out, uint8_t *actions_out_or_null,
                         int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
                         uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace, size_t workspace_bytes,
                         void *stream)
@@ -1549,12 +1384,12 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
         return G2048_ERR_ARG;
     }
     return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
-                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     alive_out, actions_out_or_null, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
                      (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace);
 }
 
 int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out, int32_t *invalid_out,
-                           int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out,
+                           int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null, uint8_t *alive_out, uint8_t *actions_out_or_null,
                            int width, int depth, int early_threshold, int mid_threshold, int max_moves, uint64_t seed,
                            uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace, size_t workspace_bytes,
                            const uint32_t *tuning4, void *stream)
@@ -1567,7 +1402,7 @@ int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *m
         return G2048_ERR_ARG;
     }
     return play_impl(boards_inout, score_inout, moves_out, valid_out, invalid_out, milestone_move_out, expanded_sum_out_or_null,
-                     alive_out, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
+                     alive_out, actions_out_or_null, width, depth, early_threshold, mid_threshold, max_moves, seed, game_id_base, n_games, opts, stream,
                      (opts & G2048_PLAY_ONE_PHASE) ? nullptr : workspace, tuning4);
 }
 
@@ -1592,23 +1427,18 @@ int g2048_device_plan(int width, size_t n_games, uint32_t *out6)
     const size_t beam_blocks = beam_resident_blocks(passes);
     out6[0] = (uint32_t)cus; out6[1] = (uint32_t)resident; out6[2] = p.helper_cap;
     out6[3] = default_helpers((uint32_t)n_games, p.helper_cap); out6[4] = (uint32_t)beam_blocks;
-#ifndef G2048_BEAM_NO_PRIO
     out6[5] = n_games <= beam_blocks ? 1u : 0u;
-#else
-    out6[5] = 0u;
-#endif
     return G2048_OK;
 }
 
 int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream)
 {
     if (n_waves == 0) return G2048_OK;
-    if (!keys_inout || n_waves > 0x7fffffffu || (key_bits != 32 && key_bits != 64 && key_bits != -32) ||
-        (key_bits == -32 && !extra_or_null)) {
+    if (!keys_inout || n_waves > 0x7fffffffu || (key_bits != 32 && key_bits != 64)) {
         g2048_set_last_error_("g2048_sort_selftest: bad arguments"); return G2048_ERR_ARG;
     }
     hipLaunchKernelGGL(sort_selftest_kernel, dim3((unsigned)n_waves), dim3(64), 0, static_cast<hipStream_t>(stream), keys_inout,
-                       extra_or_null, extra_or_null ? 1 : 0, key_bits == 64 ? 1 : key_bits == -32 ? 2 : 0);
+                       extra_or_null, extra_or_null ? 1 : 0, key_bits == 64 ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g2048_set_last_error_(hipGetErrorString(e)); return G2048_ERR_HIP; }
     return G2048_OK;

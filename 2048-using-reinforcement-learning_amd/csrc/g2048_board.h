@@ -43,7 +43,7 @@ constexpr uint32_t B7F = 0x7f7f7f7fu;
 
 // RNG domains (DESIGN.md "RNG")
 enum : uint32_t { DOM_STEP = 1, DOM_RESET = 2, DOM_BEAM = 3, DOM_SYNTH_BOARD = 4, DOM_SYNTH_ACTION = 5, DOM_EPISODE = 6, DOM_POLICY = 7,
-                  DOM_SIMULATE = 8 };
+                  DOM_SIMULATE = 8, DOM_MINIBATCH = 9 };
 
 // ---------------------------------------------------------------- intrinsics --
 // v_perm_b32: bytes of {s0:s1} (s1 = bytes 0..3, s0 = bytes 4..7) picked by the
@@ -219,36 +219,11 @@ G2048_HD Board move_env_sel(const Board &b, const DirSel &s, uint32_t &gain, uin
     return o;
 }
 
-// Both moves of one axis at once (beam kernel): vertical = (UP, DOWN), horizontal = (LEFT, RIGHT). One transpose in,
-// two slides (the second on the reversed line order), two transposes out -- cheaper than two independent moves.
-// Env semantics for both results; the agent's DOWN quirk is applied by the caller.
-// merges_fwd / merges_rev: merge events of the two moves (each frees one cell).
-G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev, uint32_t &merges_fwd, uint32_t &merges_rev)
-{
-    const Board t = transpose(b);
-    const uint32_t x0 = vertical ? b.w[0] : t.w[0], x1 = vertical ? b.w[1] : t.w[1];
-    const uint32_t x2 = vertical ? b.w[2] : t.w[2], x3 = vertical ? b.w[3] : t.w[3];
-    uint32_t F[4] = {x0, x1, x2, x3}, R[4] = {x3, x2, x1, x0};
-    (void)slide_lines(F, merges_fwd);
-    (void)slide_lines(R, merges_rev);
-    const Board f = {{F[0], F[1], F[2], F[3]}}, r = {{R[3], R[2], R[1], R[0]}};
-    const Board ft = transpose(f), rt = transpose(r);
-    fwd.w[0] = vertical ? f.w[0] : ft.w[0]; fwd.w[1] = vertical ? f.w[1] : ft.w[1];
-    fwd.w[2] = vertical ? f.w[2] : ft.w[2]; fwd.w[3] = vertical ? f.w[3] : ft.w[3];
-    rev.w[0] = vertical ? r.w[0] : rt.w[0]; rev.w[1] = vertical ? r.w[1] : rt.w[1];
-    rev.w[2] = vertical ? r.w[2] : rt.w[2]; rev.w[3] = vertical ? r.w[3] : rt.w[3];
-}
-
-G2048_HD void move_axis(const Board &b, bool vertical, Board &fwd, Board &rev)
-{
-    uint32_t mf, mr;
-    move_axis(b, vertical, fwd, rev, mf, mr);
-}
-
-// The same pair of moves through the direction network (round 3): a lane's axis never changes during a search, so its
-// three selector sets -- rows -> lines, forward lines -> rows, reversed lines -> rows -- are loop-invariant per-lane data
-// and both moves cost 24 v_perm in all: no transpose whose result half the lanes discard, no v_cndmask (move_axis above:
-// 28 v_perm + 16 v_cndmask with the agent's DOWN quirk applied by the caller). The reversed slide runs on the line order
+// Both moves of one axis at once (beam kernel: vertical = (UP, DOWN), horizontal = (LEFT, RIGHT)) through the direction network:
+// a lane's axis never changes during a search, so its three selector sets -- rows -> lines, forward lines -> rows, reversed
+// lines -> rows -- are loop-invariant per-lane data and both moves cost 24 v_perm in all: no transpose whose result half the
+// lanes discard, no v_cndmask (rounds 1-2 paired two select-based moves: 28 v_perm + 16 v_cndmask with the agent's DOWN quirk
+// applied by the caller). The reversed slide runs on the line order
 // {3,2,1,0}; its results R[k] are position 3-k, which is exactly the line order RIGHT's output selectors expect
 // (G2048_DIR_TABLE_INIT: RIGHT's input net yields LEFT's lines reversed). For the vertical axis the reverse-output
 // selectors also carry BeamSearchAgent._make_move's DOWN quirk (agents/beam_search_agent.py:209-210 vs :251-253, result =
@@ -342,31 +317,11 @@ G2048_HD bool game_over(const Board &b) { return valid_mask_env(b) == 0u; }
 // order gets a 2 (code 1) or a 4 (code 2). h is one 32-bit draw:
 // idx = ((h >> 16) * n_empty) >> 16, four iff (h & 0xffff) >= 58982.
 // No-op on a full board. Returns n_empty before the spawn.
-// Two formulations, both exact; which is faster depends on the surrounding kernel (A/B on MI355X, two builds,
-// interleaved): the select chain wins in the beam kernel (0.188 vs 0.191 ms), the prefix-sum form in the step
-// kernel, where its by-product -- the post-spawn zero flags -- also feeds the tile sums (13.33 vs 13.51 us).
-// (1) row select + k-th set flag
-G2048_HD uint32_t spawn(Board &b, uint32_t h, bool enable = true, uint32_t *zf_out = nullptr)
-{
-    const uint32_t z0 = zflag(b.w[0]), z1 = zflag(b.w[1]), z2 = zflag(b.w[2]), z3 = zflag(b.w[3]);
-    const uint32_t c0 = popc(z0), c1 = c0 + popc(z1), c2 = c1 + popc(z2), n = c2 + popc(z3);
-    const uint32_t idx = ((h >> 16) * n) >> 16;
-    const uint32_t row = (idx >= c0 ? 1u : 0u) + (idx >= c1 ? 1u : 0u) + (idx >= c2 ? 1u : 0u);
-    uint32_t z = row == 0 ? z0 : row == 1 ? z1 : row == 2 ? z2 : z3;
-    const uint32_t k = idx - (row == 0 ? 0u : row == 1 ? c0 : row == 2 ? c1 : c2);
-    z &= z - (k > 0 ? 1u : 0u);
-    z &= z - (k > 1 ? 1u : 0u);
-    z &= z - (k > 2 ? 1u : 0u);
-    const uint32_t bit = (n == 0u || !enable) ? 0u : z & (0u - z);
-    const uint32_t add = bit >> (((h & 0xffffu) >= 58982u) ? 6 : 7);
-    const uint32_t b0 = row == 0 ? bit : 0u, b1 = row == 1 ? bit : 0u, b2 = row == 2 ? bit : 0u, b3 = row == 3 ? bit : 0u;
-    b.w[0] |= row == 0 ? add : 0u; b.w[1] |= row == 1 ? add : 0u;
-    b.w[2] |= row == 2 ? add : 0u; b.w[3] |= row == 3 ? add : 0u;
-    if (zf_out) { zf_out[0] = z0 ^ b0; zf_out[1] = z1 ^ b1; zf_out[2] = z2 ^ b2; zf_out[3] = z3 ^ b3; }
-    return n;
-}
-
-// (1b) row select as in (1), then the k-th empty cell of that row by a byte-wise prefix count of its zero indicators instead
+// Two formulations, both exact (tests/hostsim checks them against each other and the oracle); which is faster depends on
+// the surrounding kernel: the row-select form in the beam kernel (a shorter dependent chain), the all-rows prefix form in the
+// step kernel, where its by-product -- the post-spawn zero flags -- also feeds the tile sums (13.33 vs 13.51 us). A third form
+// (row select + clearing k flags one by one) lost to both and is gone (profiles/r03_beam_latency.txt).
+// (1) row select, then the k-th empty cell of that row by a byte-wise prefix count of its zero indicators instead
 // of clearing k flags one by one (round 3): (z >> 7) * 0x01010101 has, in byte c, the number of empty cells in columns 0..c;
 // the cell whose count equals k + 1 is the one. A full board needs no special case: its z is 0.
 G2048_HD uint32_t spawn_rowprefix(Board &b, uint32_t h, bool enable = true, uint32_t *zf_out = nullptr)

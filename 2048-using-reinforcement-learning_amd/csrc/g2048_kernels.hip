@@ -8,10 +8,12 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 
 #include "../../include/g2048.h"
 #include "g2048_board.h"
+#include "g2048_instrument.h"
 #include "g2048_rng.h"
 
 using namespace g2048;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
 // in flight serialises load latency -> compute -> store. A block owns 256*B consecutive boards; pass k
 // of a wave touches 64 consecutive boards (1 KiB per wave-instruction).
 // NOOP_ACTIONS: action bytes above 3 move nothing, as in the reference (drop-in class); otherwise the low two bits count
-template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false, bool SELECT_DIR = false, bool NOOP_ACTIONS = false>
+template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false, bool NOOP_ACTIONS = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
                                                      uint4 *boards_out,
@@ -96,9 +98,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     // Streaming launches (two boards per lane, from 4 Mi boards on): a new wavefront issues its loads ahead of the arithmetic of
     // the older ones on its SIMD (the arbiter would serve those first) -- 152.8 -> 147.5 us per 16 Mi boards. Nothing to gain at
     // 1 Mi boards, where five phase-priority schemes stayed within +-1 % (profiles/r03_beam_priority.txt, section 10).
-#ifdef G2048_STEP_TIMING          // tools/step_timeline.py: lanes 0..2 of every wavefront write start tick, end tick and SIMD over the reward
-    const unsigned long long tm0 = wall_clock64();
-#endif
+    [[maybe_unused]] const unsigned long long tm0 = kStepTiming ? wall_clock64() : 0ull;       // (measurement builds only, tools/step_timeline.py)
     if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
@@ -133,9 +133,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         if (!(full || j < lim)) break;
         const uint64_t id = id_base + block0 + j;
         if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
-        // SELECT_DIR: the round-1 formulation (per-lane selects between transposed / reversed copies), kept for A/B only
-        const StepOut o = SELECT_DIR ? step_board(prev[k], action[k] & 3u, rng_draw(k0, k1, id, 0u))
-                        : NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u))
+        const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u))
                                        : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u));
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
@@ -150,14 +148,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
         if (REWARD_F64) rw64[j] = o.reward;
         else rw32[j] = (float)o.reward;
         flp[j] = (uint8_t)o.flags;        // bit0 DONE, bit1 VALID, bits 3..7 max code (include/g2048.h)
-#ifdef G2048_STEP_TIMING
-        if (!REWARD_F64 && k == 0) {
-            const uint32_t h = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-            const uint32_t simd = ((h >> 4) & 3u) | (((h >> 8) & 15u) << 2) | (((h >> 12) & 1u) << 6) | (((h >> 13) & 7u) << 7) | ((x & 15u) << 10);
+        if constexpr (kStepTiming && !REWARD_F64) {       // lanes 0..2 of every wavefront: start tick, end tick, SIMD over the reward
             const uint32_t l = threadIdx.x & 63u;
-            if (l < 3u) reinterpret_cast<uint32_t *>(rw32)[j] = l == 0u ? (uint32_t)tm0 : l == 1u ? (uint32_t)wall_clock64() : simd;
+            if (k == 0 && l < 3u) reinterpret_cast<uint32_t *>(rw32)[j] = l == 0u ? (uint32_t)tm0 : l == 1u ? (uint32_t)wall_clock64() : simd_id();
         }
-#endif
     }
 }
 
@@ -227,6 +221,103 @@ __global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in
     score[block0 + j] = sc;
     flags_last[block0 + j] = (uint8_t)flags;
     if (episodes_out) episodes_out[block0 + j] = episodes;
+}
+
+// ---------------------------------------------------------- one env, one record --
+// The drop-in Game2048Env (environment/game_2048.py:29-48 reset, :170-210 step, :50-57 get_state, :69-95 get_valid_moves) is
+// ONE board driven from a Python loop (train.py:55-75 calls get_valid_moves and step every iteration): what costs there is
+// launches and host round trips, not arithmetic. One launch does the whole iteration's device work: the action arrives by value
+// (no fill launch), the board and score are updated in place, and ONE 80-byte record receives everything the host mirrors need:
+// the state in the reference's layout (int32 tile values), the score, the flags, the NEXT state's valid-move mask (so that
+// get_valid_moves() is a cache read) and the f64 reward. One wavefront, lane 0 stores.
+struct EnvRecord { int32_t tiles[16]; int32_t score; uint8_t flags, valid_next, pad[2]; double reward; };
+static_assert(sizeof(EnvRecord) == G2048_ENV_RECORD_BYTES && offsetof(EnvRecord, reward) == 72, "record layout is part of the ABI");
+
+__global__ __launch_bounds__(64) void env_step_kernel(uint4 *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op,
+                                                     EnvRecord *record, uint32_t k0, uint32_t k1, uint64_t id)
+{
+    const uint4 bv = board_inout[0];
+    Board cur = {{bv.x, bv.y, bv.z, bv.w}};
+    uint32_t sc = score_inout[0], flags;
+    double reward = 0.0;
+    if (op == G2048_ENV_OP_RESET) {                               // :29-48 (keys of the RESET domain, index = epoch)
+        cur = fresh_board(rng_draw(k0, k1, id, 0u), rng_draw(k0, k1, id, 1u));
+        sc = 0u;
+        flags = max_code(cur) << G2048_FLAG_MAXCODE_SHIFT;
+    } else if (op == G2048_ENV_OP_PEEK) {                         // the record of the board as it is (after `board` was assigned)
+        flags = (max_code(cur) << G2048_FLAG_MAXCODE_SHIFT) | (game_over(cur) ? G2048_FLAG_DONE : 0u);
+    } else {                                                      // :170-210; an action outside 0..3 moves nothing (:97-114)
+        const uint32_t *d = kDirTable + 8u * (action & 3u);
+        const StepOut o = step_board_sel_noop(cur, DirSel{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]}, action > 3u,
+                                              rng_draw(k0, k1, id, 0u));
+        cur = o.board; sc += o.gain; flags = o.flags; reward = o.reward;
+    }
+    const uint32_t valid_next = valid_mask_env(cur);
+    if (threadIdx.x != 0) return;
+    board_inout[0] = make_uint4(cur.w[0], cur.w[1], cur.w[2], cur.w[3]);
+    score_inout[0] = sc;
+    int4 *tiles = reinterpret_cast<int4 *>(record->tiles);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t x = cur.w[r];
+        auto tile = [](uint32_t c) -> int { return c ? (int)(1u << c) : 0; };
+        tiles[r] = make_int4(tile(x & 0xffu), tile((x >> 8) & 0xffu), tile((x >> 16) & 0xffu), tile(x >> 24));
+    }
+    record->score = (int32_t)sc;
+    record->flags = (uint8_t)flags; record->valid_next = (uint8_t)valid_next; record->pad[0] = record->pad[1] = 0;
+    record->reward = reward;
+}
+
+// ------------------------------------------------------------ recorded games --
+// The per-move histories of the reference's run_game (evaluate_beam_search.py:44-50, :72-75, :88-97: board_history,
+// max_tiles_history, scores_history) rebuilt from a game's action bytes: the env's draws are counter-based -- move t of game g
+// spawns with (seed, STEP, t, g) whoever plays it --, so one byte per move is all g2048_play_games has to keep, and replaying
+// them reproduces every intermediate board. One lane per game; entry t of a game's history is the state BEFORE move t (entry 0:
+// the start, entry n_moves: the final state), which is the reference's list (its entry t + 1 = the state after move t).
+__global__ __launch_bounds__(kBlock) void replay_kernel(const uint4 *__restrict__ boards0, const uint32_t *__restrict__ score0,
+                                                       const unsigned long long *__restrict__ game_ids, uint64_t id_base,
+                                                       const uint8_t *__restrict__ actions, size_t actions_stride,
+                                                       const int32_t *__restrict__ n_moves, uint4 *__restrict__ boards_hist,
+                                                       uint32_t *__restrict__ score_hist, uint8_t *__restrict__ flags_hist,
+                                                       size_t hist_stride, uint64_t seed, size_t n)
+{
+    __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
+    dir_table_to_lds(s_dir);
+    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool in_range = k < n;
+    const uint64_t id = in_range ? (game_ids ? (uint64_t)game_ids[k] : id_base + k) : 0ull;
+    Board cur = in_range ? load_board(boards0, k) : Board{{0u, 0u, 0u, 0u}};
+    uint32_t sc = (in_range && score0) ? score0[k] : 0u;
+    // (never beyond the history's room, whatever the caller's counts say)
+    const uint32_t len = in_range ? (uint32_t)min((size_t)max(n_moves[k], 0), hist_stride - 1u) : 0u;
+    const uint8_t *act = actions + k * actions_stride;
+    uint4 *bh = boards_hist + k * hist_stride;
+    uint32_t *sh = score_hist ? score_hist + k * hist_stride : nullptr;
+    uint8_t *fh = flags_hist ? flags_hist + k * hist_stride : nullptr;
+    uint32_t next_action = len ? (uint32_t)act[0] : 0xffu;
+    uint32_t t = 0;
+    for (;; ++t) {                                               // t is wave-uniform: the keys of move t come from the scalar unit
+        const bool live = t < len && next_action <= 3u;          // (a byte above 3 -- 0xFF = no move -- ends this game's replay)
+        if (__ballot(live) == 0ull) break;
+        if (!live) continue;
+        const Keys ks = rng_keys(seed, DOM_STEP, (uint64_t)t);
+        const uint32_t action = next_action;
+        if (t + 1u < len) next_action = (uint32_t)act[t + 1u];   // requested before this move is computed
+        bh[t] = make_uint4(cur.w[0], cur.w[1], cur.w[2], cur.w[3]);
+        if (sh) sh[t] = sc;
+        const StepOut o = step_board_sel(cur, dir_sel(s_dir, action), rng_draw(ks.k0, ks.k1, id, 0u));
+        cur = o.board;
+        sc += o.gain;
+        if (fh) fh[t] = (uint8_t)o.flags;
+        if (t + 1u == len || next_action > 3u) {                 // the state after the last move replayed
+            bh[t + 1u] = make_uint4(cur.w[0], cur.w[1], cur.w[2], cur.w[3]);
+            if (sh) sh[t + 1u] = sc;
+        }
+    }
+    if (in_range && (len == 0u || (uint32_t)act[0] > 3u)) {      // nothing to replay: the history is the start state
+        bh[0] = make_uint4(cur.w[0], cur.w[1], cur.w[2], cur.w[3]);
+        if (sh) sh[0] = sc;
+    }
 }
 
 // ------------------------------------------------------------------ reset -----
@@ -521,6 +612,7 @@ const char *g2048_last_error(void) { return g_err; }
 // internal: lets the other translation units of this library report through the same string
 void g2048_set_last_error_(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 int g2048_abi_version(void) { return G2048_ABI_VERSION; }
+unsigned g2048_build_flags(void) { return kInstrument; }
 
 int g2048_device_count(void)
 {
@@ -541,36 +633,30 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_step: score/reward arrays misaligned");
-    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS | G2048_STEP_NOOP_ACTIONS | (7u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
+    if (opts & ~(G2048_STEP_REWARD_F64 | G2048_STEP_AUTO_RESET | G2048_STEP_RANDOM_ACTIONS | G2048_STEP_NOOP_ACTIONS | (3u << G2048_STEP_TUNE_SHIFT))) return fail(G2048_ERR_ARG, "g2048_step: unknown opts 0x%x", opts);
     const Keys k = rng_keys(seed, DOM_STEP, step_index), e = rng_keys(seed, DOM_EPISODE, step_index);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *in = static_cast<const uint4 *>(boards_in);
     uint4 *out = static_cast<uint4 *>(boards_out);
     const bool f64 = opts & G2048_STEP_REWARD_F64, ar = opts & G2048_STEP_AUTO_RESET;
     const unsigned tune = (opts >> G2048_STEP_TUNE_SHIFT) & 3u;            // 0 = default
+    if (tune == 3u) return fail(G2048_ERR_ARG, "g2048_step: tune 3 (four boards per lane) was removed: measured slower at every size");
     // default: one board per lane -- measured fastest up to a few Mi boards per launch, where the launch is short and
     // wave-level parallelism hides the load latency; from 4 Mi boards on (beyond the Infinity Cache) two boards per lane,
     // both loads in flight before the first is computed, stream 4-5 % faster (profiles/r02_step_tune.txt)
-    const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : tune == 3 ? 4 : (n >= ((size_t)1 << 22) ? 2 : kStepBoardsPerLane);
+    const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : (n >= ((size_t)1 << 22) ? 2 : kStepBoardsPerLane);
 #define G2048_LAUNCH_STEP(F, A, BB) \
     hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, in, actions, out, \
                        score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
 #define G2048_LAUNCH_STEP_B(F, A) \
-    do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else if (per_lane == 2) G2048_LAUNCH_STEP(F, A, 2); \
-         else G2048_LAUNCH_STEP(F, A, 4); } while (0)
+    do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else G2048_LAUNCH_STEP(F, A, 2); } while (0)
     if (opts & G2048_STEP_NOOP_ACTIONS) {            // reference semantics for action values outside 0..3 (drop-in class)
         if (random_actions) return fail(G2048_ERR_ARG, "g2048_step: NOOP_ACTIONS needs explicit actions");
-#define G2048_LAUNCH_NOOP(F, A) hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, false, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, \
+#define G2048_LAUNCH_NOOP(F, A) hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, \
                            in, actions, out, score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
         if (f64 && ar) G2048_LAUNCH_NOOP(true, true); else if (f64) G2048_LAUNCH_NOOP(true, false);
         else if (ar) G2048_LAUNCH_NOOP(false, true); else G2048_LAUNCH_NOOP(false, false);
 #undef G2048_LAUNCH_NOOP
-        return check_launch("g2048_step");
-    }
-    if ((opts >> G2048_STEP_TUNE_SHIFT) & 4u) {      // A/B only: direction by per-lane selects, f32 reward, no auto-reset
-        if (f64 || ar || random_actions) return fail(G2048_ERR_ARG, "g2048_step: the select-direction A/B variant is plain f32 only");
-        hipLaunchKernelGGL((step_kernel<false, false, 1, kBlock, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, in, actions,
-                           out, score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock);
         return check_launch("g2048_step");
     }
     if (random_actions) {           // uniform actions drawn in the kernel: (seed, SYNTH_ACTION, step_index, board id) >> 30
@@ -641,6 +727,36 @@ int g2048_step_many(const void *boards_in, const uint8_t *actions_stream_or_null
 #undef G2048_LAUNCH_MANY_R
 #undef G2048_LAUNCH_MANY
     return check_launch("g2048_step_many");
+}
+
+int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
+                   uint64_t index, uint64_t board_id, void *stream)
+{
+    if (!board_inout || !score_inout || !record_out) return fail(G2048_ERR_ARG, "g2048_env_step: null pointer");
+    if (!aligned16(board_inout) || !aligned4(score_inout) || !aligned16(record_out)) return fail(G2048_ERR_ARG, "g2048_env_step: misaligned pointer");
+    if (op > G2048_ENV_OP_PEEK) return fail(G2048_ERR_ARG, "g2048_env_step: unknown op %u", op);
+    const Keys k = rng_keys(seed, op == G2048_ENV_OP_RESET ? DOM_RESET : DOM_STEP, index);
+    hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint4 *>(board_inout),
+                       score_inout, action, op, static_cast<EnvRecord *>(record_out), k.k0, k.k1, board_id);
+    return check_launch("g2048_env_step");
+}
+
+int g2048_replay_games(const void *boards0, const uint32_t *score0_or_null, const uint64_t *game_ids_or_null, uint64_t game_id_base,
+                       const uint8_t *actions, size_t actions_stride, const int32_t *n_moves, void *boards_hist_out,
+                       uint32_t *score_hist_out_or_null, uint8_t *flags_hist_out_or_null, size_t hist_stride, uint64_t seed,
+                       size_t n, void *stream)
+{
+    if (n == 0) return G2048_OK;
+    if (!boards0 || !actions || !n_moves || !boards_hist_out) return fail(G2048_ERR_ARG, "g2048_replay_games: null pointer");
+    if (!aligned16(boards0) || !aligned16(boards_hist_out) || !aligned4(n_moves) || (score0_or_null && !aligned4(score0_or_null)) ||
+        (score_hist_out_or_null && !aligned4(score_hist_out_or_null)) || (game_ids_or_null && (reinterpret_cast<uintptr_t>(game_ids_or_null) & 7u)))
+        return fail(G2048_ERR_ARG, "g2048_replay_games: misaligned array");
+    if (hist_stride == 0) return fail(G2048_ERR_ARG, "g2048_replay_games: hist_stride must be at least 1 (max moves + 1)");
+    hipLaunchKernelGGL(replay_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4 *>(boards0), score0_or_null, reinterpret_cast<const unsigned long long *>(game_ids_or_null),
+                       game_id_base, actions, actions_stride, n_moves, static_cast<uint4 *>(boards_hist_out), score_hist_out_or_null,
+                       flags_hist_out_or_null, hist_stride, seed, n);
+    return check_launch("g2048_replay_games");
 }
 
 int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch, uint64_t board_id_base,

@@ -137,6 +137,76 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
     }
 }
 
+// ---------------------------------------------------------------- minibatch ---------
+// PPOMemory.sample (agents/ppo_agent.py:21-50: batch_size distinct transitions, np.random.choice(replace=False)) and the first
+// lines of PPOAgent.update (:342-354: normalize states and next states, tensors on the device) for a trajectory buffer that
+// already lives in HBM. Sample j of the batch is transition P(j), P a keyed bijection of 0 .. n-1: a four-round Feistel
+// network on 2h bits (2^2h >= n) walked until it lands below n -- cycle walking; the walk ends because P permutes the 2^2h
+// values and j itself is below n --, so the batch is a sample WITHOUT replacement whatever its size, with no table, no sort and
+// no host round trip. Four lanes per sample (one board row = one float4 of each observation per lane).
+__host__ __device__ inline uint32_t minibatch_round(uint32_t x, uint32_t key)
+{
+    uint32_t h = x ^ key;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+__host__ __device__ inline uint64_t minibatch_index(uint64_t j, uint64_t n, uint32_t half_bits, uint32_t k0, uint32_t k1)
+{
+    const uint32_t mask = half_bits >= 32u ? 0xffffffffu : (1u << half_bits) - 1u;
+    uint64_t x = j;
+    do {
+        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+        uint32_t t;
+        t = l ^ (minibatch_round(r, k0) & mask); l = r; r = t;
+        t = l ^ (minibatch_round(r, k1) & mask); l = r; r = t;
+        t = l ^ (minibatch_round(r, k0 * 0x9E3779B1u + 1u) & mask); l = r; r = t;
+        t = l ^ (minibatch_round(r, k1 * 0x85EBCA77u + 2u) & mask); l = r; r = t;
+        x = ((uint64_t)l << half_bits) | r;
+    } while (x >= n);
+    return x;
+}
+
+template <int OBS_KIND, bool REWARD_F64>
+__global__ __launch_bounds__(256) void minibatch_kernel(const void *__restrict__ obs, const uint8_t *__restrict__ actions,
+                                                       const float *__restrict__ logp, const void *__restrict__ rewards,
+                                                       const uint32_t *__restrict__ next_rows, const uint8_t *__restrict__ flags,
+                                                       uint64_t n, uint64_t batch, uint32_t half_bits, uint32_t k0, uint32_t k1,
+                                                       float4 *__restrict__ states_out, long long *__restrict__ actions_out,
+                                                       float *__restrict__ logp_out, float *__restrict__ rewards_out,
+                                                       float4 *__restrict__ next_states_out, float *__restrict__ dones_out,
+                                                       long long *__restrict__ indices_out)
+{
+    const uint64_t gidx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t j = gidx >> 2;
+    const uint32_t r = (uint32_t)gidx & 3u;
+    if (j >= batch) return;
+    const uint64_t i = minibatch_index(j, n, half_bits, k0, k1);
+    float4 st;
+    if (OBS_KIND == G2048_OBS_F32) {
+        st = static_cast<const float4 *>(obs)[4u * i + r];
+    } else {
+        const uint2 h = static_cast<const uint2 *>(obs)[4u * i + r];
+        if (OBS_KIND == G2048_OBS_BF16) {
+            st = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                             __uint_as_float(h.y & 0xffff0000u));
+        } else {
+            st = make_float4(__half2float(__ushort_as_half((unsigned short)(h.x & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(h.x >> 16))),
+                             __half2float(__ushort_as_half((unsigned short)(h.y & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(h.y >> 16))));
+        }
+    }
+    states_out[gidx] = st;
+    const uint32_t x = next_rows[4u * i + r];                         // PPOAgent.normalize_state (:184-195): float32(code) / float32(15)
+    next_states_out[gidx] = make_float4((float)(x & 0xffu) / 15.0f, (float)((x >> 8) & 0xffu) / 15.0f,
+                                        (float)((x >> 16) & 0xffu) / 15.0f, (float)(x >> 24) / 15.0f);
+    if (r != 0u) return;
+    actions_out[j] = (long long)actions[i];
+    logp_out[j] = logp[i];
+    rewards_out[j] = REWARD_F64 ? (float)static_cast<const double *>(rewards)[i] : static_cast<const float *>(rewards)[i];
+    dones_out[j] = (flags[i] & G2048_FLAG_DONE) ? 1.0f : 0.0f;
+    if (indices_out) indices_out[j] = (long long)i;
+}
+
 // ---------------------------------------------------------------- running maximum ---
 // prev_highest[i] = max(carry, maxcode[0..i)), maxcode[i] = flags[i] >> 3 (the max log2 code after transition i).
 // 4096 transitions per block: 256 threads x 16 consecutive flag bytes (one 16-byte load).
@@ -398,6 +468,39 @@ int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t 
                        obs_next_out_or_null, mask4_next_out_or_null, static_cast<uint4 *>(next_boards_out_or_null),
                        state_maxcode_out_or_null, seed, step_index, step_counter_or_null, env_id_base, n, opts);
     return check_launch("g2048_rollout_step");
+}
+
+int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *actions, const float *log_probs, const void *rewards,
+                           uint32_t rewards_f64, const void *next_boards, const uint8_t *flags, size_t n_transitions, size_t batch,
+                           uint64_t seed, uint64_t sample_index, float *states_out, int64_t *actions_out, float *old_log_probs_out,
+                           float *rewards_out, float *next_states_out, float *dones_out, int64_t *indices_out_or_null, void *stream)
+{
+    if (batch == 0) return G2048_OK;
+    if (!obs || !actions || !log_probs || !rewards || !next_boards || !flags || !states_out || !actions_out || !old_log_probs_out ||
+        !rewards_out || !next_states_out || !dones_out)
+        return fail(G2048_ERR_ARG, "g2048_minibatch_gather: null pointer");
+    if (batch > n_transitions) return fail(G2048_ERR_ARG, "g2048_minibatch_gather: batch larger than the buffer (sampling is without replacement)");
+    if (obs_kind > G2048_OBS_BF16) return fail(G2048_ERR_ARG, "g2048_minibatch_gather: unknown observation dtype");
+    if (!aligned(obs, 16) || !aligned(next_boards, 16) || !aligned(states_out, 16) || !aligned(next_states_out, 16) ||
+        !aligned(log_probs, 4) || !aligned(rewards, rewards_f64 ? 8 : 4) || !aligned(actions_out, 8) || !aligned(old_log_probs_out, 4) ||
+        !aligned(rewards_out, 4) || !aligned(dones_out, 4) || (indices_out_or_null && !aligned(indices_out_or_null, 8)))
+        return fail(G2048_ERR_ARG, "g2048_minibatch_gather: misaligned array");
+    uint32_t bits = 1;
+    while (bits < 64u && ((uint64_t)1 << bits) < (uint64_t)n_transitions) ++bits;
+    const uint32_t half_bits = (bits + 1u) / 2u;
+    const Keys k = rng_keys(seed, DOM_MINIBATCH, sample_index);
+    if (batch > ((size_t)1 << 36)) return fail(G2048_ERR_ARG, "g2048_minibatch_gather: batch too large for one launch");
+    const dim3 grid((unsigned)((batch * 4u + 255u) / 256u));
+#define G2048_LAUNCH_MB(K, F) hipLaunchKernelGGL((minibatch_kernel<K, F>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), obs, actions, \
+                              log_probs, rewards, static_cast<const uint32_t *>(next_boards), flags, (uint64_t)n_transitions, (uint64_t)batch, \
+                              half_bits, k.k0, k.k1, reinterpret_cast<float4 *>(states_out), reinterpret_cast<long long *>(actions_out), \
+                              old_log_probs_out, rewards_out, reinterpret_cast<float4 *>(next_states_out), dones_out, \
+                              reinterpret_cast<long long *>(indices_out_or_null))
+    if (obs_kind == G2048_OBS_F32) { if (rewards_f64) G2048_LAUNCH_MB(0, true); else G2048_LAUNCH_MB(0, false); }
+    else if (obs_kind == G2048_OBS_F16) { if (rewards_f64) G2048_LAUNCH_MB(1, true); else G2048_LAUNCH_MB(1, false); }
+    else { if (rewards_f64) G2048_LAUNCH_MB(2, true); else G2048_LAUNCH_MB(2, false); }
+#undef G2048_LAUNCH_MB
+    return check_launch("g2048_minibatch_gather");
 }
 
 size_t g2048_shaping_scan_workspace(size_t n) { return ((n + kScanTile - 1) / kScanTile + 1) * sizeof(uint32_t); }

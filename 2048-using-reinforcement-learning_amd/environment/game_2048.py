@@ -1,15 +1,17 @@
 """Drop-in for the reference's environment/game_2048.py: same class name, methods, return types.
 
-One board living on the GPU and stepped by the same HIP kernel that steps millions
-(`g2048_step` with n = 1). It exists so that scripts written against the reference
-(`train.py`-shaped loops, `agents/ppo_agent.py`) run unchanged; for throughput use
-`g2048.VecGame2048`. Differences from the reference, all deliberate:
+One board living on the GPU and stepped by the same device arithmetic that steps millions. It exists so
+that scripts written against the reference (`train.py`-shaped loops, `agents/ppo_agent.py`) run unchanged;
+for throughput use `g2048.VecGame2048`. A `train.py` iteration (`get_valid_moves()` + `step()`, train.py:55-75)
+costs ONE launch and ONE synchronisation: `g2048_env_step` takes the action by value, steps the board in place and
+writes one 80-byte record -- state as int32 tiles, score, flags, the NEXT state's valid-move mask, f64 reward -- that
+all host mirrors are refreshed from, so `get_valid_moves()` is a cache read. Differences from the reference, all deliberate:
   * tile spawns come from the engine's counter RNG, not from Python's global `random`
     (the seed defaults to one draw from `random`, so `random.seed(k)` still pins a run);
   * size != 4 raises (the reference's agents hard-code 4x4: beam_search_agent.py:69,378);
   * step(action) with an action outside 0..3 is, as in the reference (`_execute_move` has no branch for it, :97-114), a
-    move that changes nothing: invalid, no spawn, the invalid-move reward (G2048_STEP_NOOP_ACTIONS; the batched front-ends
-    use the low two bits of the action byte unless asked otherwise).
+    move that changes nothing: invalid, no spawn, the invalid-move reward (the batched front-ends use the low two bits of the
+    action byte unless asked otherwise: G2048_STEP_NOOP_ACTIONS).
 """
 import random
 
@@ -23,7 +25,11 @@ from g2048 import ops
 class Game2048Env:
     ACTIONS = {0: "LEFT", 1: "UP", 2: "RIGHT", 3: "DOWN"}      # reference :11-16
 
-    def __init__(self, size=4, seed=None, device="cuda"):
+    # where the 80-byte step record lands: "host" = the kernel writes it straight into pinned (device-visible) host memory, so
+    # an iteration is one launch + one stream synchronisation; "device" = device memory + one device->host copy
+    RECORD = "host"
+
+    def __init__(self, size=4, seed=None, device="cuda", record=None):
         if size != 4:
             raise ValueError("Game2048Env: only size=4 is supported by the MI355X engine")
         self.size = size
@@ -33,21 +39,20 @@ class Game2048Env:
         L.lib()
         self.seed = random.getrandbits(63) if seed is None else int(seed)
         self._boards = torch.zeros((1, 16), dtype=torch.uint8, device=self.device)
-        self._action = torch.zeros(1, dtype=torch.uint8, device=self.device)
-        # one 80-byte device record receives everything a step produces, so a step costs ONE device->host
-        # copy: [0:64) tiles int32[16] | [64:68) score int32 | [68] flags | [72:80) reward float64
-        self._rec = torch.zeros(80, dtype=torch.uint8, device=self.device)
-        self._tiles = self._rec[0:64].view(torch.int32).view(1, 16)
-        self._scores = self._rec[64:68].view(torch.int32)
-        self._flags = self._rec[68:69]
-        self._reward = self._rec[72:80].view(torch.float64)
-        self._host = torch.zeros(80, dtype=torch.uint8).pin_memory()
+        self._scores = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # ONE 80-byte record receives everything an iteration produces (g2048_env_step): [0:64) tiles int32[16] | [64:68) score
+        # int32 | [68] flags | [69] valid-move mask of the new state | [72:80) reward float64
+        self._host = torch.zeros(L.ENV_RECORD_BYTES, dtype=torch.uint8).pin_memory()
+        self._record_on_host = (record or self.RECORD) == "host"
+        self._rec = self._host if self._record_on_host else torch.zeros(L.ENV_RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        self._h = self._host.numpy()
         self._t = 0
         self._epoch = 0
+        self._mask = None           # valid-move mask of the current board, if the last record still describes it
         self.highest_tile = 0
         self.reset()
 
-    # -- state mirrors (host copies refreshed after every device call) -------
+    # -- state mirrors (host copies refreshed by every device call) ----------
     @property
     def board(self):
         return self._board_np
@@ -57,6 +62,7 @@ class Game2048Env:
         tiles = torch.as_tensor(np.ascontiguousarray(value, dtype=np.int32).reshape(1, 16), device=self.device)
         ops.pack(tiles, out=self._boards)
         self._board_np = np.array(value, dtype=np.int32).reshape(4, 4).copy()
+        self._mask = None           # the cached mask described the old board
 
     @property
     def score(self):
@@ -67,21 +73,23 @@ class Game2048Env:
         self._score = value
         self._scores.fill_(int(value))
 
-    def _pull(self):
-        """Refresh the host mirrors; returns (flags, reward) of the last step."""
-        ops.unpack(self._boards, out=self._tiles)
-        self._host.copy_(self._rec, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        h = self._host.numpy()
+    def _run(self, op, index, action=0):
+        """One g2048_env_step launch + one synchronisation; refreshes the host mirrors. Returns (flags, reward)."""
+        ops.env_step(self._boards, self._scores, self._rec, self.seed, index, 0, action, op)
+        stream = torch.cuda.current_stream(self.device)
+        if not self._record_on_host:
+            self._host.copy_(self._rec, non_blocking=True)
+        stream.synchronize()
+        h = self._h
         self._board_np = h[0:64].view(np.int32).reshape(4, 4).copy()
         self._score = np.int32(h[64:68].view(np.int32)[0])
+        self._mask = int(h[69])
         return int(h[68]), np.float64(h[72:80].view(np.float64)[0])
 
     # -- reference API ---------------------------------------------------------
     def reset(self):                                           # reference :29-48
-        ops.reset(1, self.seed, self._epoch, 0, boards=self._boards, scores=self._scores)
+        self._run(L.ENV_OP_RESET, self._epoch)
         self._epoch += 1
-        self._pull()
         self._score = 0
         self.game_over = False
         self.highest_tile = np.max(self._board_np)
@@ -91,16 +99,16 @@ class Game2048Env:
         return self._board_np.flatten()
 
     def get_valid_moves(self):                                 # reference :69-95
-        m = int(ops.valid_moves(self._boards).item())
+        if self._mask is None:      # `board` was assigned since the last step: ask the device once (no move, no draw)
+            self._run(L.ENV_OP_PEEK, 0)
+        m = self._mask
         return [bool((m >> a) & 1) for a in range(4)]
 
     def step(self, action):                                    # reference :170-210
         a = int(action)
-        self._action.fill_(a if a in (0, 1, 2, 3) else 255)        # anything else moves nothing, as the reference's :97-114
-        ops.step(self._boards, self._action, self._scores, self.seed, self._t, 0, out=self._boards,
-                 reward=self._reward, flags=self._flags, reward_f64=True, noop_actions=True)
+        # anything but 0..3 moves nothing, as the reference's _execute_move (:97-114)
+        flags, reward = self._run(L.ENV_OP_STEP, self._t, a if a in (0, 1, 2, 3) else 255)
         self._t += 1
-        flags, reward = self._pull()
         self.game_over = bool(flags & L.FLAG_DONE)
         current_highest = np.max(self._board_np)
         if current_highest > self.highest_tile:

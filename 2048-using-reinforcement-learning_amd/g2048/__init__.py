@@ -8,7 +8,8 @@ look-alikes of the reference's classes live where the reference keeps them:
 """
 from . import _lib, ops                      # noqa: F401
 from .vec import VecGame2048, BatchedBeamSearch   # noqa: F401
-from .evaluate import evaluate_beam_search, evaluate_beam_search_sharded           # noqa: F401
+from .evaluate import evaluate_beam_search, evaluate_beam_search_sharded, save_moveset, save_game_data   # noqa: F401
 from .rollout import RolloutCollector, masked_sample  # noqa: F401
 
-__all__ = ["ops", "VecGame2048", "BatchedBeamSearch", "evaluate_beam_search", "evaluate_beam_search_sharded", "RolloutCollector", "masked_sample"]
+__all__ = ["ops", "VecGame2048", "BatchedBeamSearch", "evaluate_beam_search", "evaluate_beam_search_sharded", "save_moveset",
+           "save_game_data", "RolloutCollector", "masked_sample"]

@@ -13,7 +13,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB = os.environ.get("G2048_LIB") or os.path.join(CSRC, "libg2048_hip.so")     # G2048_LIB: A/B builds only (tools/)
 SOURCES = ["g2048_kernels.hip", "g2048_beam.hip", "g2048_rollout.hip"]
-HEADERS = ["g2048_board.h", "g2048_rng.h", os.path.join("..", "..", "include", "g2048.h")]
+PUBLIC_HEADER = os.path.join(CSRC, "..", "..", "include", "g2048.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 
@@ -22,7 +22,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    # every file a source can include is a dependency: whatever lies in csrc/ (sources, headers, .inc) + the public header
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".hpp"))] + [PUBLIC_HEADER]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

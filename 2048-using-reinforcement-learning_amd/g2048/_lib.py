@@ -14,7 +14,7 @@ from . import _build
 _lib = None
 
 OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
 STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS, STEP_NOOP_ACTIONS = 0x01, 0x02, 0x04, 0x08
 VALID_ENV, VALID_AGENT = 0, 1
@@ -26,11 +26,13 @@ BEAM_MAX_WIDTH = 128
 KEYBLOCK_WORDS = 16
 ROLLOUT_OBS_SHIFT, OBS_F32, OBS_F16, OBS_BF16 = 4, 0, 1, 2
 SEEN_SLOT_BYTES = 32
+ENV_RECORD_BYTES, ENV_OP_STEP, ENV_OP_RESET, ENV_OP_PEEK = 80, 0, 1, 2
 
 _vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {
     "g2048_last_error": (C.c_char_p, []),
     "g2048_abi_version": (_int, []),
+    "g2048_build_flags": (C.c_uint, []),
     "g2048_device_count": (_int, []),
     "g2048_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _u32, _vp]),
     "g2048_step_many": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u32, _u64, _sz, _u32, _vp]),
@@ -48,12 +50,16 @@ SIGNATURES = {
     "g2048_sample_actions": (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
     "g2048_simulate_move": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "g2048_simulate_move_sampled": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _sz, _vp]),
-    "g2048_play_games": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp]),
+    "g2048_play_games": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp]),
     "g2048_play_games_workspace": (_sz, [_sz]),
-    "g2048_play_games_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp, _sz,
-                                  _vp]),
-    "g2048_play_games_tuned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp,
-                                     _sz, _vp, _vp]),
+    "g2048_play_games_ws": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32, _vp,
+                                  _sz, _vp]),
+    "g2048_play_games_tuned": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _u64, _u64, _sz, _u32,
+                                     _vp, _sz, _vp, _vp]),
+    "g2048_replay_games": (_int, [_vp, _vp, _vp, _u64, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _u64, _sz, _vp]),
+    "g2048_env_step": (_int, [_vp, _vp, _u32, _u32, _vp, _u64, _u64, _u64, _vp]),
+    "g2048_minibatch_gather": (_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp]),
     "g2048_launch_plan": (_int, [_int, _int, _sz, _vp]),
     "g2048_device_plan": (_int, [_int, _sz, _vp]),
     "g2048_pack_i32": (_int, [_vp, _vp, _sz, _vp]),
@@ -100,6 +106,13 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.g2048_abi_version() != ABI_VERSION:
             raise RuntimeError("g2048: ABI version mismatch (library %d, binding %d)" % (L.g2048_abi_version(), ABI_VERSION))
+        flags = int(L.g2048_build_flags())
+        if flags and os.environ.get("G2048_ALLOW_INSTRUMENTED") != "1":
+            # a measurement build (csrc/g2048_instrument.h) overwrites real outputs with clock ticks: only the timeline tools,
+            # which set G2048_ALLOW_INSTRUMENTED=1 themselves, may load one
+            raise RuntimeError("g2048: %s is an instrumented measurement build (g2048_build_flags() = 0x%x); its outputs are "
+                               "not results -- refusing to load it (tools/*_timeline.py opt in with G2048_ALLOW_INSTRUMENTED=1)"
+                               % (path, flags))
         _lib = L
     return _lib
 

@@ -66,7 +66,7 @@ def step(boards, actions, scores, seed, step_index, id_base=0, out=None, reward=
     L.require_device_tensor(reward, rdt, None, "reward")
     L.require_device_tensor(flags, torch.uint8, None, "flags")
     opts = ((L.STEP_REWARD_F64 if reward_f64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
-            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | (L.STEP_NOOP_ACTIONS if noop_actions else 0) | ((int(tune) & 7) << 8))
+            (L.STEP_RANDOM_ACTIONS if random_actions else 0) | (L.STEP_NOOP_ACTIONS if noop_actions else 0) | ((int(tune) & 3) << 8))
     act_ptr = None if random_actions else actions.data_ptr()
     if keyblock is not None:        # keys (and so seed / step index) come from the device key block
         L.call(dev, L.lib().g2048_step_dyn, boards.data_ptr(), act_ptr, out.data_ptr(), scores.data_ptr(),
@@ -89,7 +89,7 @@ class PreparedStep:
         self._keep = (boards, actions, scores, out, reward, flags)
         self.device = boards.device
         opts = ((L.STEP_REWARD_F64 if reward.dtype == torch.float64 else 0) | (L.STEP_AUTO_RESET if auto_reset else 0) |
-                ((int(tune) & 7) << 8))
+                ((int(tune) & 3) << 8))
         self._fn = L.lib().g2048_step
         self._head = (boards.data_ptr(), actions.data_ptr(), out.data_ptr(), scores.data_ptr(), reward.data_ptr(), flags.data_ptr(),
                       L.u64(seed))
@@ -499,19 +499,82 @@ def metrics(boards, scores=None, flags=None, expanded=None, out=None):
     return out
 
 
-_BEAM_WS = {}
-_BEAM_HIST = {}     # (device, stream) -> [history tensor, batch size, calls so far]
+class BeamHistory:
+    """The caller-owned state of the depth-balanced block order (include/g2048.h, g2048_beam_get_action_hist): the history
+    buffer the blocks of one call file their games in for the next call, and the call index. One object serves ONE sequence of
+    calls on one stream of one device; `BatchedBeamSearch` owns one, `beam_get_action(balanced_order=True)` keeps one per
+    (device, stream) in a small registry. Thread-safe: advancing the index and enqueueing the launch happen under the object's
+    lock, so two host threads that share it still hand the library consecutive indices in launch order (the device side
+    degrades to caller order on any inconsistency anyway -- results never depend on the order)."""
+
+    def __init__(self, device="cuda"):
+        import threading
+        self.device = torch.device(device)
+        self.lock = threading.Lock()
+        self.buf, self.n, self.calls = None, 0, 0
+
+    def _prepare(self, n, need):
+        """(buffer, call index) for the next call over n roots; the lock is held by the caller."""
+        if self.buf is None or self.buf.numel() < need or self.n != n:
+            if self.buf is None or self.buf.numel() < need:
+                self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.buf.zero_()
+            self.n, self.calls = n, 0
+        self.calls += 1
+        if self.calls >= 0x7fffffff:
+            self.buf.zero_()
+            self.calls = 1
+        return self.buf, self.calls
+
+
+class _PerStream:
+    """Scratch kept per (device, stream) for the convenience path of beam_get_action: at most `cap` entries, least recently
+    used evicted (a stream handle that is never used again does not pin its buffer for the life of the process)."""
+
+    def __init__(self, cap=16):
+        import collections
+        import threading
+        self.cap, self.lock, self.items = cap, threading.Lock(), collections.OrderedDict()
+
+    def get(self, key, make):
+        with self.lock:
+            v = self.items.get(key)
+            if v is None:
+                v = self.items[key] = make()
+                while len(self.items) > self.cap:
+                    self.items.popitem(last=False)
+            else:
+                self.items.move_to_end(key)
+            return v
+
+
+_BEAM_WS = _PerStream()
+_BEAM_HIST = _PerStream()
+
+
+def _dev_index(dev):
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def _size_query(dev, fn, n):
+    """The library's workspace / history size queries depend on the CURRENT device's compute-unit count: ask with the tensors'
+    device current, as the launch itself will run."""
+    idx = _dev_index(dev)
+    if torch.cuda.current_device() == idx:
+        return int(fn(n))
+    with torch.cuda.device(idx):
+        return int(fn(n))
 
 
 def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, mid_threshold=1024,
                     seed=0x2048, step_index=0, game_id_base=0, fixed_down=False, want_expanded=False, keyblock=None,
-                    rank_by_counting=False, balanced_order=True,
-                    out=None):
+                    rank_by_counting=False, balanced_order=True, out=None, history=None):
     """BeamSearchAgent.get_action for every root (agents/beam_search_agent.py:71-181).
     Returns (actions uint8, probs float32[, expanded int32]). balanced_order: from 4096 roots on the blocks take the games in
-    a depth-balanced order (same results, shorter launch): True = the order the previous call on this stream left behind
-    (no launch of its own; the first call of a sequence runs in caller order), "sort" = an order from this call's own
-    roots (one more small launch), False = caller order. Scratch is kept per (device, stream)."""
+    a depth-balanced order (same results, shorter launch): True = the order the previous call left behind in `history` (a
+    BeamHistory the caller owns; None: one kept per (device, stream), shared by whoever calls on that stream -- safe from any
+    host thread; the first call of a sequence runs in caller order), "sort" = an order from this call's own roots (one more
+    small launch), False = caller order."""
     L.require_device_tensor(roots, torch.uint8, (16,), "roots")
     n = roots.shape[0]
     if not (1 <= int(width) <= L.BEAM_MAX_WIDTH):
@@ -535,49 +598,48 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
     if keyblock is not None:
         L.call(dev, L.lib().g2048_beam_get_action_dyn, *head, keyblock.words.data_ptr(), *tail)
     else:
-        # the depth-balanced block order of large batches. Default: the order of the PREVIOUS call on this stream (its blocks
-        # file their games into a history buffer, g2048_beam_get_action_hist -- no launch of its own); the buffer is caller-owned
-        # like every other one: one zero-filled tensor per (device, stream), zeroed again when the batch size changes. With
-        # balanced_order="sort" the order comes from this call's own roots (beam_order_kernel, one more launch). Neither while the
-        # stream is being captured: the cached tensor must not come from a graph's private pool.
+        # the depth-balanced block order of large batches. Default: the order of the PREVIOUS call of the same sequence (its
+        # blocks file their games into the history buffer, g2048_beam_get_action_hist -- no launch of its own). With
+        # balanced_order="sort" the order comes from this call's own roots (beam_order_kernel, one more launch). Neither while
+        # the stream is being captured: the cached tensors must not come from a graph's private pool.
         capturing = torch.cuda.is_current_stream_capturing()
-        key = (dev.index, tail[-1])
+        key = (_dev_index(dev), tail[-1])
         if balanced_order == "sort":
-            need = 0 if capturing else int(L.lib().g2048_beam_workspace_bytes(n))
+            need = 0 if capturing else _size_query(dev, L.lib().g2048_beam_workspace_bytes, n)
             ws = None
             if need:
-                ws = _BEAM_WS.get(key)
+                box = _BEAM_WS.get(key, lambda: [None])
+                ws = box[0]
                 if ws is None or ws.numel() < need:
-                    ws = _BEAM_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    ws = box[0] = torch.empty(need, dtype=torch.uint8, device=dev)
             L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
                    ws.data_ptr() if ws is not None else None, need, tail[-1])
         else:
-            need = 0 if (not balanced_order or capturing) else int(L.lib().g2048_beam_history_bytes(n))
-            hist, call_index = None, 0
-            if need:
-                st = _BEAM_HIST.get(key)
-                if st is None or st[0].numel() < need or st[1] != n:
-                    buf = st[0] if (st is not None and st[0].numel() >= need) else torch.empty(need, dtype=torch.uint8, device=dev)
-                    buf.zero_()
-                    st = _BEAM_HIST[key] = [buf, n, 0]
-                st[2] += 1
-                if st[2] >= 0x7fffffff:
-                    st[0].zero_(); st[2] = 1
-                hist, call_index = st[0], st[2]
-            L.call(dev, L.lib().g2048_beam_get_action_hist, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
-                   hist.data_ptr() if hist is not None else None, need, call_index, tail[-1])
+            need = 0 if (not balanced_order or capturing) else _size_query(dev, L.lib().g2048_beam_history_bytes, n)
+            if not need:
+                L.call(dev, L.lib().g2048_beam_get_action_hist, *head, L.u64(seed), L.u64(step_index), *tail[:-1], None, 0, 0, tail[-1])
+            else:
+                h = history if history is not None else _BEAM_HIST.get(key, lambda: BeamHistory(dev))
+                if _dev_index(h.device) != key[0]:
+                    raise ValueError("g2048: this BeamHistory belongs to %s, the roots live on %s" % (h.device, dev))
+                with h.lock:        # index + enqueue together: the library wants consecutive indices in launch order
+                    buf, call_index = h._prepare(n, need)
+                    L.call(dev, L.lib().g2048_beam_get_action_hist, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
+                           buf.data_ptr(), need, call_index, tail[-1])
     return (actions, probs, expanded) if (want_expanded or (out is not None and expanded is not None)) else (actions, probs)
 
 
 def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512, mid_threshold=1024, seed=0x2048,
-               game_id_base=0, fixed_down=False, one_phase=False, rank_by_counting=False, tuning=None):
+               game_id_base=0, fixed_down=False, one_phase=False, rank_by_counting=False, tuning=None, want_actions=False):
     """Every game played to completion in ONE launch (beam get_action -> env step fused per game, reference
     run_evaluation.py:48-69): one wavefront owns a game; helper wavefronts of the same launch search the boards the next
     moves can start from ahead of time, for the games that are left when the chip empties (g2048_beam.hip;
     one_phase=True plays without them -- the games are identical). boards / scores are updated in place. Returns a dict
     of per-game tensors: moves, valid_moves, invalid_moves (int32), milestone_move (int32 (n,8), -1 = never), expanded
     (int64), alive (uint8). tuning = (helpers, games_left, stuck, wait_us): the helper-wavefront parameters given explicitly
-    (g2048_play_games_tuned; measurements and tests -- the games are the same for every setting)."""
+    (g2048_play_games_tuned; measurements and tests -- the games are the same for every setting). want_actions: also
+    "actions", uint8 (n, max_moves): the move-set of every game, 0xFF from its end on (train.py:51,67,140-142; the input of
+    `replay_games`)."""
     L.require_device_tensor(boards, torch.uint8, (16,), "boards")
     _require_scores(scores)
     n = boards.shape[0]
@@ -590,12 +652,15 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
         "milestone_move": torch.full((n, 8), -1, dtype=torch.int32, device=dev),
         "expanded": torch.zeros(n, dtype=torch.int64, device=dev), "alive": torch.zeros(n, dtype=torch.uint8, device=dev),
     }
+    if want_actions:
+        out["actions"] = torch.empty((n, int(max_moves)), dtype=torch.uint8, device=dev)     # (the library fills it with 0xFF)
     # the helpers' request slots: caller-owned scratch, like every other buffer of the interface
-    ws_bytes = 0 if one_phase else int(L.lib().g2048_play_games_workspace(n))
+    ws_bytes = 0 if one_phase else _size_query(dev, L.lib().g2048_play_games_workspace, n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     args = (boards.data_ptr(), scores.data_ptr(), out["moves"].data_ptr(),
             out["valid_moves"].data_ptr(), out["invalid_moves"].data_ptr(), out["milestone_move"].data_ptr(),
-            out["expanded"].data_ptr(), out["alive"].data_ptr(), int(width), int(depth), int(early_threshold),
+            out["expanded"].data_ptr(), out["alive"].data_ptr(), out["actions"].data_ptr() if want_actions else None,
+            int(width), int(depth), int(early_threshold),
             int(mid_threshold), int(max_moves), L.u64(seed), L.u64(game_id_base), n,
             (L.BEAM_FIXED_DOWN if fixed_down else 0) | (L.PLAY_ONE_PHASE if one_phase else 0) |
             (L.BEAM_RANK_BY_COUNTING if rank_by_counting else 0),
@@ -606,6 +671,88 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
         L.call(dev, L.lib().g2048_play_games_tuned, *args, ctypes.cast(t4, ctypes.c_void_p), L.stream_ptr(dev))
     else:
         L.call(dev, L.lib().g2048_play_games_ws, *args, L.stream_ptr(dev))
+    return out
+
+
+def replay_games(boards0, actions, n_moves, seed, game_ids=None, game_id_base=0, scores0=None):
+    """Recorded games replayed into their per-move histories (g2048_replay_games; reference evaluate_beam_search.py:44-50,
+    :72-75: board_history / scores_history / max_tiles_history of run_game). boards0 uint8 (k,16): where each game started;
+    actions uint8 (k, stride): its action bytes as `play_games(want_actions=True)` wrote them; n_moves int32 (k,); game_ids
+    int64 (k,) = the GLOBAL ids the games were played under (None: game_id_base + row). Returns (boards_hist uint8
+    (k, L+1, 16), score_hist int32 (k, L+1), flags_hist uint8 (k, L+1)), L = the longest game; entry t = the state before move
+    t, entry n_moves = the final state; entries past a game's end are zero."""
+    L.require_device_tensor(boards0, torch.uint8, (16,), "boards0")
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    L.require_device_tensor(n_moves, torch.int32, None, "n_moves")
+    k, dev = boards0.shape[0], boards0.device
+    if actions.dim() != 2 or actions.shape[0] != k or n_moves.shape[0] != k:
+        raise ValueError("g2048: actions must be (k, stride) and n_moves (k,) for k start boards")
+    if game_ids is not None:
+        L.require_device_tensor(game_ids, torch.int64, None, "game_ids")
+        if game_ids.shape[0] != k:
+            raise ValueError("g2048: game_ids must have one id per game")
+    if scores0 is not None:
+        _require_scores(scores0)
+    longest = min(int(n_moves.max().item()), actions.shape[1]) if k else 0       # (one host sync: the histories are sized by it)
+    hist = longest + 1
+    boards_hist = torch.zeros((k, hist, 16), dtype=torch.uint8, device=dev)
+    score_hist = torch.zeros((k, hist), dtype=torch.int32, device=dev)
+    flags_hist = torch.zeros((k, hist), dtype=torch.uint8, device=dev)
+    L.call(dev, L.lib().g2048_replay_games, boards0.data_ptr(), scores0.data_ptr() if scores0 is not None else None,
+           game_ids.data_ptr() if game_ids is not None else None, L.u64(game_id_base), actions.data_ptr(), actions.shape[1],
+           n_moves.data_ptr(), boards_hist.data_ptr(), score_hist.data_ptr(), flags_hist.data_ptr(), hist, L.u64(seed), k,
+           L.stream_ptr(dev))
+    return boards_hist, score_hist, flags_hist
+
+
+def env_step(board, score, record, seed, index, board_id=0, action=0, op=None):
+    """One iteration of ONE env in one launch (g2048_env_step): op ENV_OP_STEP (default) / ENV_OP_RESET / ENV_OP_PEEK. board uint8
+    (1,16) and score int32 (1,) are updated in place; `record` -- uint8 (80,), device memory or pinned host memory -- receives
+    the state as int32 tiles, the score, the flags, the next valid-move mask and the f64 reward (include/g2048.h)."""
+    L.require_device_tensor(board, torch.uint8, (16,), "board")
+    _require_scores(score)
+    if not isinstance(record, torch.Tensor) or record.dtype != torch.uint8 or record.numel() < L.ENV_RECORD_BYTES or not record.is_contiguous():
+        raise TypeError("g2048: record must be a contiguous uint8 tensor of at least %d bytes" % L.ENV_RECORD_BYTES)
+    if not (record.is_cuda or record.is_pinned()):
+        raise RuntimeError("g2048: record must live in device memory or in pinned host memory")
+    dev = board.device
+    L.call(dev, L.lib().g2048_env_step, board.data_ptr(), score.data_ptr(), int(action) & 0xFFFFFFFF,
+           L.ENV_OP_STEP if op is None else int(op), record.data_ptr(), L.u64(seed), L.u64(index), L.u64(board_id), L.stream_ptr(dev))
+
+
+def minibatch_gather(obs, actions, log_probs, rewards, next_boards, flags, batch, seed, sample_index, want_indices=False):
+    """PPOMemory.sample + the head of PPOAgent.update (agents/ppo_agent.py:21-50, :342-354) on a device-resident trajectory
+    (g2048_minibatch_gather): `batch` distinct transitions drawn and gathered by one launch, no host sync. Inputs are flat over
+    the transitions: obs (n,16) float32 / float16 / bfloat16, actions uint8, log_probs float32, rewards float32 or float64,
+    next_boards uint8 (n,16) (before any auto-reset), flags uint8. Returns dict(states, actions, old_log_probs, rewards,
+    next_states, dones[, indices])."""
+    if obs.dtype not in _OBS_KIND:
+        raise TypeError("g2048: obs must be float32, float16 or bfloat16")
+    L.require_device_tensor(obs, obs.dtype, (16,), "obs")
+    n, dev = obs.shape[0], obs.device
+    L.require_device_tensor(actions, torch.uint8, None, "actions")
+    L.require_device_tensor(log_probs, torch.float32, None, "log_probs")
+    if rewards.dtype not in (torch.float32, torch.float64):
+        raise TypeError("g2048: rewards must be float32 or float64")
+    L.require_device_tensor(rewards, rewards.dtype, None, "rewards")
+    L.require_device_tensor(next_boards, torch.uint8, (16,), "next_boards")
+    L.require_device_tensor(flags, torch.uint8, None, "flags")
+    if not (actions.shape[0] == log_probs.shape[0] == rewards.shape[0] == next_boards.shape[0] == flags.shape[0] == n):
+        raise ValueError("g2048: all trajectory arrays must have one entry per transition")
+    batch = min(int(batch), n)                      # PPOMemory.sample: a batch larger than the buffer is the whole buffer
+    out = {"states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
+           "actions": torch.empty(batch, dtype=torch.int64, device=dev),
+           "old_log_probs": torch.empty(batch, dtype=torch.float32, device=dev),
+           "rewards": torch.empty(batch, dtype=torch.float32, device=dev),
+           "next_states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
+           "dones": torch.empty(batch, dtype=torch.float32, device=dev)}
+    if want_indices:
+        out["indices"] = torch.empty(batch, dtype=torch.int64, device=dev)
+    L.call(dev, L.lib().g2048_minibatch_gather, obs.data_ptr(), _OBS_KIND[obs.dtype], actions.data_ptr(), log_probs.data_ptr(),
+           rewards.data_ptr(), int(rewards.dtype == torch.float64), next_boards.data_ptr(), flags.data_ptr(), n, batch, L.u64(seed),
+           L.u64(sample_index), out["states"].data_ptr(), out["actions"].data_ptr(), out["old_log_probs"].data_ptr(),
+           out["rewards"].data_ptr(), out["next_states"].data_ptr(), out["dones"].data_ptr(),
+           out["indices"].data_ptr() if want_indices else None, L.stream_ptr(dev))
     return out
 
 

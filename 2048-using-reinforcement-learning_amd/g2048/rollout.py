@@ -44,7 +44,8 @@ class RolloutCollector:
     sampler="torch" keeps the unfused reference-style path (torch masked_sample + one launch per piece)."""
 
     def __init__(self, n_envs, n_steps, policy, device="cuda", seed=0x2048, id_base=0, shaping=False,
-                 generator=None, sampler="fused", obs_dtype=torch.float32, use_graph=True, seen_capacity_log2=20):
+                 generator=None, sampler="fused", obs_dtype=torch.float32, use_graph=True, seen_capacity_log2=20,
+                 minibatches=False):
         self.n, self.T = int(n_envs), int(n_steps)
         self.device = torch.device(device)
         self.policy = policy
@@ -54,6 +55,11 @@ class RolloutCollector:
             raise ValueError("sampler must be 'fused' (g2048_rollout_step, counter RNG) or 'torch' (masked_sample)")
         if shaping and sampler != "fused":
             raise ValueError("shaping=True needs sampler='fused' (the fused step records what remember() consumes)")
+        if minibatches and sampler != "fused":
+            raise ValueError("minibatches=True needs sampler='fused' (the fused step records the next states sample() gathers)")
+        self.minibatches = bool(minibatches) or self.shaping     # sample() needs the next states before auto-reset, as shaping does
+        self._samples = 0           # sample() calls so far (RNG index of the minibatch permutation)
+        self._seed = int(seed)
         self.sampler = sampler
         self.env = VecGame2048(self.n, device=self.device, seed=seed, id_base=id_base, auto_reset=True)
         d, T, n = self.device, self.T, self.n
@@ -76,6 +82,8 @@ class RolloutCollector:
         else:
             self.rewards64 = self.next_boards = self.state_maxcode = self.shaped = self.seen = None
             self.rewards = torch.empty((T, n), dtype=torch.float32, device=d)
+            if self.minibatches:
+                self.next_boards = torch.empty((T, n, 16), dtype=torch.uint8, device=d)
         self.env_steps = 0
         self.use_graph = bool(use_graph) and sampler == "fused"
         self._graph = None
@@ -97,7 +105,7 @@ class RolloutCollector:
                          mask=self._masks[t], out=env._spare, actions=self.actions[t], prob=self.logp[t],
                          reward=self.rewards64[t] if self.shaping else self.rewards[t], flags=self.flags[t],
                          obs_next=self._obs[t + 1], mask_next=self._masks[t + 1],
-                         next_boards=self.next_boards[t] if self.shaping else None,
+                         next_boards=self.next_boards[t] if self.next_boards is not None else None,
                          state_maxcode=self.state_maxcode[t] if self.shaping else None, auto_reset=True,
                          step_counter=counter)
         env.boards, env._spare = env._spare, env.boards
@@ -191,6 +199,10 @@ class RolloutCollector:
             T, n = self.T, self.n
             ops.remember_shaping(self.seen, self.next_boards.view(T * n, 16), self.state_maxcode.view(T * n),
                                  self.flags.view(T * n), self.rewards64.view(T * n), out=self.shaped.view(T * n))
+            self._collects_since_check = getattr(self, "_collects_since_check", 0) + 1
+            if self._collects_since_check >= self.CHECK_EVERY:     # the table's overflow flag: one host sync every so often
+                self.check()
+        self._filled = True
         self.env_steps += self.T * self.n
         return {
             "obs": self.obs, "valid_mask": self.masks, "actions": self.actions, "log_prob": self.logp,
@@ -199,3 +211,37 @@ class RolloutCollector:
             "max_code": self.flags >> L.FLAG_MAXCODE_SHIFT, "shaping": self.shaped, "last_obs": self.last_obs,
             "last_valid_mask": self._masks[self.T],
         }
+
+    CHECK_EVERY = 16        # collect() calls between two looks at the seen-states table's overflow flag (shaping=True)
+
+    def check(self):
+        """Raise if the seen-states table of the shaping terms ever overflowed (ops.SeenStates.assert_ok: one host sync).
+        collect() calls it every CHECK_EVERY collects; call it yourself after the last collect of a run."""
+        self._collects_since_check = 0
+        if self.seen is not None:
+            self.seen.assert_ok()
+
+    def sample(self, batch_size, generator=None, want_indices=False):
+        """PPOMemory.sample(batch_size) (agents/ppo_agent.py:21-50) over the transitions of the last collect(), as the tensors
+        PPOAgent.update builds from it (:342-354): dict(states float32 (B,16) normalized, actions int64 (B,), old_log_probs
+        float32 (B,), rewards float32 (B,) -- the shaped reward remember() stores when shaping=True, else the env's --,
+        next_states float32 (B,16) normalized (the state the env returned, before any auto-reset), dones float32 (B,)).
+        B distinct transitions (without replacement; a batch larger than the buffer is the whole buffer), drawn and gathered
+        by ONE launch (g2048_minibatch_gather), no host synchronisation. The draw is keyed by (the collector's seed, the number
+        of sample() calls so far); generator: a CPU torch.Generator to take the key from instead."""
+        if not self.minibatches:
+            raise RuntimeError("RolloutCollector.sample needs minibatches=True (or shaping=True): the next states are not recorded")
+        if not getattr(self, "_filled", False):
+            raise RuntimeError("RolloutCollector.sample: collect() first")
+        seed = self._seed
+        if generator is not None:
+            if generator.device.type != "cpu":
+                raise ValueError("sample(generator=...): a CPU generator (its draw must not synchronise the device)")
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+        T, n = self.T, self.n
+        rewards = self.shaped if self.shaping else self.rewards
+        out = ops.minibatch_gather(self.obs.reshape(T * n, 16), self.actions.view(T * n), self.logp.view(T * n),
+                                   rewards.view(T * n), self.next_boards.view(T * n, 16), self.flags.view(T * n),
+                                   batch_size, seed, self._samples, want_indices=want_indices)
+        self._samples += 1
+        return out

@@ -133,11 +133,14 @@ class BatchedBeamSearch:
         self.early_game_threshold, self.mid_game_threshold = int(early_game_threshold), int(mid_game_threshold)
         self.seed, self.fixed_down = int(seed), bool(fixed_down)
         self.decisions = 0
+        self._history = None        # ops.BeamHistory of this agent's call sequence (the depth-balanced block order of large batches)
 
     def get_actions(self, boards, valid_mask=None, game_id_base=0, want_expanded=False):
         """boards uint8 (n,16). Returns (actions uint8, probs float32[, expanded])."""
+        if self._history is None or ops._dev_index(self._history.device) != ops._dev_index(boards.device):
+            self._history = ops.BeamHistory(boards.device)
         res = ops.beam_get_action(boards, self.beam_width, self.search_depth, valid_mask, self.early_game_threshold,
                                   self.mid_game_threshold, self.seed, self.decisions, game_id_base, self.fixed_down,
-                                  want_expanded)
+                                  want_expanded, history=self._history)
         self.decisions += 1
         return res

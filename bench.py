@@ -459,14 +459,22 @@ def main():
             batches.append((b0.elapsed_time(b1) * 1e-3, int(torch.stack(exps).sum().item())))
         bsec, total_exp = min(batches)
         beam_mean = sum(x / t for t, x in batches) / len(batches)
-        result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games)",
-                          "value": total_exp / bsec, "unit": "expansions/s", "value_mean_of_3_batches": beam_mean,
+        beam_best = total_exp / bsec
+        bsec_mean = sum(t for t, _ in batches) / len(batches)
+        # N > 1: every rank searched its own 4096 roots (games shard like boards); the job's figure is all ranks' expansions over
+        # the slowest rank's mean batch time
+        job_exp = world * total_exp if world == 1 else int(gdist.reduce_metrics(torch.tensor([total_exp], dtype=torch.int64, device=dev))[0].item())
+        job_sec = gdist.max_over_ranks(bsec_mean, dev)
+        result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games per GPU)",
+                          "value": beam_mean if world == 1 else job_exp / job_sec, "unit": "expansions/s",
+                          "value_best_of_3_batches": beam_best, "n_gpus": world,
                           "timing": "HIP event pair around 20 calls queued back to back (one beam kernel each; the blocks take the games in the "
-                                    "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); best of three "
-                                    "such batches (rounds 1-2: one batch), their mean beside it",
-                          "decisions_per_s": BEAM_GAMES * breps / bsec, "ms_per_batch_decision": bsec / breps * 1e3,
-                          "gbs_equivalent_29B": total_exp / bsec * BEAM_BYTES_PER_EXPANSION / 1e9,
-                          "gbs_equivalent_29B_frac_of_hbm_peak": total_exp / bsec * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
+                                    "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); `value` = mean of three "
+                                    "such batches (round 3 reported the best of three: 6.94e10 best / 6.80e10 mean then; rounds 1-2 one batch)",
+                          "decisions_per_s": BEAM_GAMES * breps / bsec_mean, "ms_per_batch_decision": bsec_mean / breps * 1e3,
+                          "ms_per_batch_decision_best": bsec / breps * 1e3,
+                          "gbs_equivalent_29B": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9,
+                          "gbs_equivalent_29B_frac_of_hbm_peak": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
                           "gbs_equivalent_note": "SURVEY 8(d): 29 B per expansion if the beam lived in HBM; the search keeps it in LDS "
                                                  "(16 B in, 5 B out per decision), so this is a comparability figure, not traffic",
                           "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
@@ -486,12 +494,23 @@ def main():
             n_simd = props.multi_processor_count * SIMDS_PER_CU      # 256 CUs x 4 on MI355X; taken from the device
             clock_ghz = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
             peak = n_simd * clock_ghz / cyc             # G wave-instructions / s
-            ach = insts / (bsec / breps) / 1e9
+            ach = insts / bsec_mean * breps / 1e9            # (priced on the mean batch, like `value`)
             result["beam"]["roofline"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
                                           "frac": ach / peak, "valu_wave_instructions_per_launch": insts,
                                           "issue_cycles_per_instruction": cyc, "simds": n_simd, "clock_ghz": clock_ghz,
                                           "source": "instruction count from a recorded rocprofv3 SQ_INSTS_VALU pass (%s); "
                                                     "time measured in this run" % pj.get("source", "profiles/pmc_beam.json")}
+
+        # BASELINE's metric has two halves; the driver's record keeps `roofline` and `cpu_baseline` whole, so a compact copy of the
+        # beam half lives there too (nested, and as flat scalars in case nested objects are dropped)
+        br = result["beam"].get("roofline", {})
+        compact = {"value": result["beam"]["value"], "unit": "expansions/s", "value_best_of_3_batches": beam_best,
+                   "ms_per_batch_decision": bsec_mean / breps * 1e3, "kernel": "beam_kernel<2>",
+                   "valu_issue_frac": br.get("frac"), "gbs_equivalent_29B_frac": result["beam"]["gbs_equivalent_29B_frac_of_hbm_peak"],
+                   "expansions_per_decision": total_exp / (BEAM_GAMES * breps), "games": BEAM_GAMES, "width": BEAM_WIDTH, "depth": BEAM_DEPTH}
+        result["roofline"]["beam"] = compact
+        for k in ("value", "ms_per_batch_decision", "valu_issue_frac", "gbs_equivalent_29B_frac", "expansions_per_decision"):
+            result["roofline"]["beam_" + k] = compact[k]
 
     # ---- evaluation leg: 4096 beam-search games (w=20, d=30) played to completion, fused per game
     if not args.no_evaluation and not args.no_beam and world == 1:
@@ -510,6 +529,14 @@ def main():
                                 "expansions_per_s": sm["expansions_per_s"], "rate_2048_or_more": sm["rate_2048_or_more"],
                                 "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
                                                                                                 "average_score": 18945.6}}
+        evh = play(BEAM_GAMES, histories="best5")           # the same evaluation with the action stream recorded + five games replayed
+        result["evaluation"]["seconds_with_action_stream_and_best5_histories"] = evh["elapsed_s"]
+        result["evaluation"]["same_games_with_action_stream"] = evh["scores"] == ev["scores"] and evh["moves"] == ev["moves"]
+        ec = {"seconds": ev["elapsed_s"], "moves": ev["total_moves"], "same_games_without_helpers": result["evaluation"]["same_games_without_helpers"],
+              "seconds_without_helper_wavefronts": ev1["elapsed_s"], "expansions_per_s": sm["expansions_per_s"], "games": BEAM_GAMES}
+        result["roofline"]["evaluation"] = ec
+        for k in ("seconds", "moves", "same_games_without_helpers"):
+            result["roofline"]["evaluation_" + k] = ec[k]
 
     # ---- sharded evaluation (N > 1): every rank plays 512 games of one evaluation, one all-gather of the per-game table.
     # A failure here must not cost the headline line: it is reported, not raised.
@@ -669,6 +696,24 @@ def main():
                                                    "(oracle/pyref.py), auto-reset",
                                          "calibration": "the reference's own Game2048Env ran at 0.88x this env's rate on "
                                                         "the same core in the build container (2.55e3 vs 2.92e3 steps/s)"}
+        # config 1 (the reference's own CPU-runnable case) through the drop-in class: a train.py-shaped iteration
+        # (get_valid_moves + step, train.py:55-75) = one g2048_env_step launch + one synchronisation
+        from environment.game_2048 import Game2048Env
+        denv = Game2048Env(seed=SEED)
+        for i in range(200):
+            denv.get_valid_moves(); denv.step(i & 3)
+        d0 = time.perf_counter(); dsteps = 0
+        while dsteps < 4000:
+            denv.get_valid_moves()
+            if denv.step(dsteps & 3)[2]:
+                denv.reset()
+            dsteps += 1
+        drate = dsteps / (time.perf_counter() - d0)
+        result["cpu_baseline_python"]["drop_in_steps_per_s"] = drate
+        result["cpu_baseline_python"]["drop_in_note"] = ("environment.game_2048.Game2048Env on the GPU, one board, get_valid_moves() + step() "
+                                                         "per iteration: one g2048_env_step launch + one synchronisation")
+        result["cpu_baseline"]["config1_drop_in_steps_per_s"] = drate
+        result["cpu_baseline"]["config1_reference_style_python_steps_per_s"] = prate
         # the last CPU pass doubles as a full-size parity check of what the GPU just computed
         one_step(W + passes - 1)
         torch.cuda.synchronize()
@@ -697,12 +742,27 @@ def main():
                                                                       "sample": "%d batch decisions over the same 4096 roots, %.1f s"
                                                                                 % (da, seca)} if every > many else None),
                                               **info}
+            cb = result["beam"]["cpu_baseline"]
+            result["cpu_baseline"]["beam"] = {"value": cb["value"], "unit": "expansions/s", "cores": cb["cores"], "kind": "port",
+                                              "one_thread": cb["one_thread"]["value"], "sample": cb["sample"]}
+            result["cpu_baseline"]["beam_value"], result["cpu_baseline"]["beam_cores"] = cb["value"], cb["cores"]
+            result["cpu_baseline"]["beam_one_thread_value"] = cb["one_thread"]["value"]
+            result["cpu_baseline"]["one_thread_value"] = result["cpu_baseline"]["one_thread"]["value"]
             a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
                                           game_id_base=0, want_expanded=True)
             assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(e.cpu().numpy().astype(np.uint32), oe), \
                 "GPU beam != oracle"
 
     if rank == 0:
+        # the numbers of BASELINE's two-part metric once more at the END of the line (a log that keeps only a tail keeps these)
+        result["headline"] = {"board_steps_per_s": result["value"], "ms_per_step": result["ms_per_step"], "n_gpus": world,
+                              "roofline_frac": result["roofline"]["frac"], "step_kernel_us": result["roofline"]["kernel_us"],
+                              "beam_expansions_per_s": (result.get("beam") or {}).get("value"),
+                              "beam_ms_per_batch_decision": (result.get("beam") or {}).get("ms_per_batch_decision"),
+                              "beam_valu_issue_frac": ((result.get("beam") or {}).get("roofline") or {}).get("frac"),
+                              "evaluation_seconds": (result.get("evaluation") or {}).get("seconds"),
+                              "cpu_board_steps_per_s": (result.get("cpu_baseline") or {}).get("value"),
+                              "cpu_beam_expansions_per_s": ((result.get("beam") or {}).get("cpu_baseline") or {}).get("value")}
         print(json.dumps(result))
     if world > 1:
         import torch.distributed as dist

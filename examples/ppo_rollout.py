@@ -5,7 +5,10 @@
 
 The policy is any torch module mapping float32 (N,16) observations to action probabilities (N,4) -- or
 (probs, value); here a small MLP. Everything between the policy's outputs and its next inputs (masked sampling,
-env step with auto-reset, reward, observation encoding) runs in HIP kernels; nothing crosses PCIe."""
+env step with auto-reset, reward, observation encoding) runs in HIP kernels; nothing crosses PCIe.
+Then one reference-style update: `RolloutCollector.sample(batch)` is PPOMemory.sample + the tensor preparation of
+PPOAgent.update (agents/ppo_agent.py:21-50, :342-354) as ONE gather launch on the device, and the loss below is the
+reference's (:356-400) on stock torch modules -- the learner stays the unchanged consumer."""
 import argparse
 import os
 import sys
@@ -20,6 +23,8 @@ import g2048
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=128)
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--epochs", type=int, default=4)
 a = ap.parse_args()
 
 
@@ -34,7 +39,8 @@ class ActorCritic(nn.Module):
         return torch.softmax(self.pi(h), -1), self.v(h)
 
 
-rc = g2048.RolloutCollector(a.envs, a.steps, ActorCritic().cuda().eval(), seed=1, shaping=True)
+net = ActorCritic().cuda().eval()
+rc = g2048.RolloutCollector(a.envs, a.steps, net, seed=1, shaping=True)
 rc.collect()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 traj = rc.collect()
@@ -42,3 +48,25 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("%d env-steps in %.3f s = %.3g env-steps/s" % (a.envs * a.steps, dt, a.envs * a.steps / dt))
 print("obs", tuple(traj["obs"].shape), "rewards mean %.3f" % float(traj["rewards"].mean()),
       "episodes finished", int(traj["dones"].sum()), "max tile seen", 1 << int(traj["max_code"].max()))
+
+# ---- one PPO update in the reference's form (agents/ppo_agent.py:336-420), on a minibatch gathered on the device
+gamma, clip_epsilon, value_coef, entropy_coef = 0.99, 0.2, 0.5, 0.01
+opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+mb = rc.sample(a.batch)                 # states / next_states normalized float32 (B,16), actions int64, old log-probs, shaped rewards, dones
+with torch.no_grad():
+    values, next_values = net(mb["states"])[1].squeeze(-1), net(mb["next_states"])[1].squeeze(-1)
+    returns = mb["rewards"] + gamma * next_values * (1 - mb["dones"])
+    adv = returns - values
+    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+net.train()
+for epoch in range(a.epochs):
+    probs, value_pred = net(mb["states"])
+    dist = torch.distributions.Categorical(probs=probs)
+    ratio = torch.exp(dist.log_prob(mb["actions"]) - mb["old_log_probs"])
+    actor_loss = -torch.min(ratio * adv, torch.clamp(ratio, 1 - clip_epsilon, 1 + clip_epsilon) * adv).mean()
+    value_loss = torch.nn.functional.mse_loss(value_pred.squeeze(-1), returns)
+    loss = actor_loss + value_coef * value_loss - entropy_coef * dist.entropy().mean()
+    opt.zero_grad(); loss.backward(); opt.step()
+net.eval()
+rc.check()
+print("update on %d sampled transitions (of %d): loss %.4f after %d epochs" % (mb["actions"].shape[0], a.envs * a.steps, float(loss), a.epochs))

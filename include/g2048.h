@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 2        /* 2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan, g2048_beam_get_action_hist; no env hook) */
+#define G2048_ABI_VERSION 3        /* 3: round 4 (actions_out of the g2048_play_games family, g2048_replay_games, g2048_env_step,
+                                      g2048_minibatch_gather, g2048_build_flags; the A/B variants of g2048_step / g2048_sort_selftest gone)
+                                      2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan,
+                                      g2048_beam_get_action_hist; no env hook) */
 
 enum {
     G2048_OK = 0,
@@ -65,8 +68,8 @@ enum {
                                           _execute_move (game_2048.py:97-114) treats values other than 0..3; without this
                                           flag only the low two bits of the byte are looked at */
 
-/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant, 0 = library default, 1/2/3 = 1/2/4;
- * bit 10 (f32 reward, no auto-reset only) selects the direction handling by per-lane selects instead of the selector table */
+/* tuning only (results identical): bits 8..9 pick the boards-per-lane variant: 0 = library default (one board per lane, two
+ * from 4 Mi boards per launch on), 1 = one, 2 = two */
 #define G2048_STEP_TUNE_SHIFT  8
 
 /* opts of g2048_valid_moves */
@@ -101,6 +104,9 @@ enum {
 
 const char *g2048_last_error(void);
 int g2048_abi_version(void);
+/* 0 for the product library. Non-zero: a measurement build (csrc/g2048_instrument.h: bit 0 beam timeline, bit 1 evaluation
+ * timeline, bit 2 step timeline) that overwrites real outputs with clock ticks -- never use its results. */
+unsigned g2048_build_flags(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 int g2048_device_count(void);
 
@@ -227,17 +233,36 @@ int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void
  * the caller (64-byte aligned; NULL = play without helpers), g2048_play_games from hipMallocAsync on `stream`.
  * Outputs per game: final board / score (in place), moves played, valid / invalid move counts,
  * milestone_move_out[g][0..8) = move at which tiles 64..8192 first appeared (-1 = never), total children expanded
- * (optional), alive_out[g] = 1 if the game hit max_moves without finishing. */
+ * (optional), alive_out[g] = 1 if the game hit max_moves without finishing.
+ * actions_out_or_null (ABI 3): the move-set of every game -- what train.py:51,67 collects in `moveset` and :140-142 writes to
+ * *_best_moveset_tile_N.txt --, n_games rows of max_moves bytes: actions_out[g * max_moves + t] = the action of move t (0..3),
+ * 0xFF from the game's end on (the library fills the array with 0xFF before the launch). One byte per move is also all that is
+ * needed to rebuild the per-move histories of evaluate_beam_search.py:44-50, :72-75 afterwards: g2048_replay_games. The bytes do
+ * not depend on helper wavefronts, tuning or the ranking switch. */
 int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                      int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
-                     uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
-                     uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream);
+                     uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
+                     int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
+                     void *stream);
 size_t g2048_play_games_workspace(size_t n_games);
 int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                         int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
-                        uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
-                        uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
+                        int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Recorded games replayed into the per-move histories of the reference's run_game (evaluate_beam_search.py:44-50, :72-75,
+ * :88-97: board_history, max_tiles_history, scores_history; :185-196 game_N_data.json): game k starts from boards0[k] with score
+ * score0_or_null[k] (NULL: 0) and plays actions[k * actions_stride + t], t = 0 .. n_moves[k] - 1, with the draw of
+ * g2048_step(step_index = t, board id = game_ids_or_null[k], or game_id_base + k) -- exactly the moves g2048_play_games made
+ * when it wrote those bytes; an action byte above 3 (0xFF = no move) ends that game's replay early. Outputs, hist_stride
+ * entries per game (hist_stride > the longest game): boards_hist_out[k * hist_stride + t] = the board BEFORE move t (t = 0 the
+ * start, t = n_moves[k] the final board), score_hist_out likewise, flags_hist_out[k * hist_stride + t] = the flags byte of move
+ * t (DONE / VALID / max code after the move: bits 3..7 give max_tiles_history). Entries past a game's end are left untouched. */
+int g2048_replay_games(const void *boards0, const uint32_t *score0_or_null, const uint64_t *game_ids_or_null, uint64_t game_id_base,
+                       const uint8_t *actions, size_t actions_stride, const int32_t *n_moves, void *boards_hist_out,
+                       uint32_t *score_hist_out_or_null, uint8_t *flags_hist_out_or_null, size_t hist_stride, uint64_t seed,
+                       size_t n, void *stream);
 
 /* g2048_play_games_ws with the helper-wavefront parameters given explicitly -- a measurement / test interface (the games are
  * the same for every setting; only the time changes). tuning4 = { helper wavefronts (clamped to 8 per game and to the
@@ -247,9 +272,9 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
  * max(n / 8, 256), 16, 150 }. */
 int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                            int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
-                           uint8_t *alive_out, int width, int depth, int early_threshold, int mid_threshold, int max_moves,
-                           uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
-                           size_t workspace_bytes, const uint32_t *tuning4, void *stream);
+                           uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
+                           int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
+                           void *workspace, size_t workspace_bytes, const uint32_t *tuning4, void *stream);
 
 /* The launch arithmetic the library derives from the device's size, as a pure host function (no launch, no allocation):
  * out4 = { SIMD row length beam batches are dealt in (4 per compute unit), smallest batch that gets the depth-balanced
@@ -263,6 +288,21 @@ int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_ga
  * default helper wavefronts for n_games, blocks of the beam kernel the device holds at once, 1 if a g2048_beam_get_action
  * launch of n_games runs with issue priority by remaining levels (every block resident at once), else 0 }. */
 int g2048_device_plan(int width, size_t n_games, uint32_t *out6);
+
+/* ONE env driven from a host loop -- the drop-in Game2048Env of train.py:55-75 -- in one launch per iteration: op STEP =
+ * Game2048Env.step(action) (environment/game_2048.py:170-210; an action outside 0..3 moves nothing, :97-114; draw (seed, STEP,
+ * index, board_id)), op RESET = Game2048Env.reset() (:29-48; draws (seed, RESET, index, board_id)), op PEEK = nothing moves.
+ * board_inout (16 bytes) / score_inout are updated in place, and record_out -- G2048_ENV_RECORD_BYTES bytes of device memory or
+ * of pinned, device-visible host memory, 16-byte aligned -- receives everything the host mirrors of the env need, so that an
+ * iteration costs one launch and one copy: [0,64) the state as int32 tile values (get_state, :50-57), [64,68) int32 score,
+ * [68] the flags byte (DONE / VALID / max code), [69] the valid-move mask of the NEW state (get_valid_moves, :69-95, for the
+ * next iteration), [72,80) the f64 reward (:212-277; 0.0 for RESET / PEEK). */
+#define G2048_ENV_RECORD_BYTES 80
+#define G2048_ENV_OP_STEP  0u
+#define G2048_ENV_OP_RESET 1u
+#define G2048_ENV_OP_PEEK  2u
+int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
+                   uint64_t index, uint64_t board_id, void *stream);
 
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
 int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
@@ -328,6 +368,20 @@ int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t 
                        const unsigned long long *step_counter_or_null, uint64_t env_id_base, size_t n, uint32_t opts,
                        void *stream);
 
+/* ---- PPOMemory.sample (agents/ppo_agent.py:21-50) + the head of PPOAgent.update (:342-354) on a device-resident buffer -----
+ * `batch` DISTINCT transitions out of n_transitions (np.random.choice(len, batch, replace=False)): sample j is transition P(j),
+ * P a bijection of 0 .. n_transitions-1 keyed by (seed, MINIBATCH, sample_index) -- a Feistel network walked until it lands in
+ * range --, drawn and gathered by ONE launch with no host round trip. Inputs are the flattened trajectory arrays of a rollout:
+ * obs ([n][16] float32 / float16 / bfloat16 per obs_kind = G2048_OBS_*, the normalized states the policy saw), actions (uint8),
+ * log_probs (float32), rewards (float32, or float64 when rewards_f64 -- e.g. the shaped reward remember() stores), next_boards
+ * (the next states BEFORE any auto-reset, as g2048_rollout_step writes them) and flags. Outputs, what update() turns the sample
+ * into: states_out float32 [batch][16], actions_out int64, old_log_probs_out float32, rewards_out float32, next_states_out
+ * float32 [batch][16] = normalize_state(next state) (:184-195), dones_out float32 (1.0 = done), and optionally the indices. */
+int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *actions, const float *log_probs, const void *rewards,
+                           uint32_t rewards_f64, const void *next_boards, const uint8_t *flags, size_t n_transitions, size_t batch,
+                           uint64_t seed, uint64_t sample_index, float *states_out, int64_t *actions_out, float *old_log_probs_out,
+                           float *rewards_out, float *next_states_out, float *dones_out, int64_t *indices_out_or_null, void *stream);
+
 /* ---- PPOAgent.remember reward shaping (agents/ppo_agent.py:234-269) for an ORDERED batch of n transitions ------------
  * The reference calls remember() once per transition, and two of its terms carry state from call to call: the
  * "new highest tile" bonus (:241-246, self.highest_tile_seen) and the novelty bonus (:259-262, self.seen_states).
@@ -368,9 +422,7 @@ int g2048_shaping_apply(const void *next_boards, const uint8_t *state_maxcode, c
 int g2048_selftest(uint32_t *result_out, void *stream);
 /* the beam kernel's ranking network on its own (tests): every 64 keys of keys_inout become the 64 largest, descending, of
  * those 64 and -- if extra_or_null is given -- 16 more per block (0 = no key; all other keys distinct and > 0).
- * key_bits = 32: uint32 keys; 64: uint64 keys stored as (low word, high word), the network of the f64-score levels;
- * -32: the pair network of the lane-resident search -- extra holds 64 more uint32 keys per block, and lanes 0..31 of every
- * block receive the 32 largest of its 128 keys, descending (lanes 32..63: unspecified; 0 = no key, the others distinct). */
+ * key_bits = 32: uint32 keys; 64: uint64 keys stored as (low word, high word), the network of the f64-score levels. */
 int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream);
 
 #ifdef __cplusplus

@@ -36,7 +36,7 @@ def test_header_symbols_exported(built):
     assert set(names) == set(built.SIGNATURES), "python binding table and header disagree"
     hdr = open(os.path.join(REPO, "include", "g2048.h")).read()
     version = int(re.search(r"#define G2048_ABI_VERSION (\d+)", hdr).group(1))
-    assert version == 2 and built.lib().g2048_abi_version() == version == built.ABI_VERSION       # bumped whenever the entry points change
+    assert version == 3 and built.lib().g2048_abi_version() == version == built.ABI_VERSION       # bumped whenever the entry points change
     assert built.lib().g2048_device_count() >= 0
 
 
@@ -191,3 +191,61 @@ def test_drop_in_import_layout_with_reference_behind():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()[-3:]
     assert lines[0].startswith(PKG) and lines[1].startswith(PKG) and lines[2].startswith("/root/reference")
+
+
+def test_round4_entry_points_validate_without_device(built):
+    """The entry points added with ABI 3 reject bad arguments before any device call (status -1, a message)."""
+    L = built.lib()
+    assert L.g2048_build_flags() == 0, "the product library must not be an instrumented measurement build"
+    assert L.g2048_replay_games(None, None, None, 0, None, 0, None, None, None, None, 0, 0, 4, None) == -1
+    assert b"null pointer" in L.g2048_last_error()
+    assert L.g2048_replay_games(None, None, None, 0, None, 0, None, None, None, None, 0, 0, 0, None) == 0      # n = 0: nothing to do
+    assert L.g2048_env_step(None, None, 0, 0, None, 0, 0, 0, None) == -1
+    buf = (C.c_uint8 * 256)()
+    base = (C.addressof(buf) + 15) & ~15
+    assert L.g2048_env_step(base, base + 16, 0, 3, base + 32, 0, 0, 0, None) == -1 and b"unknown op" in L.g2048_last_error()
+    assert L.g2048_env_step(base + 1, base + 16, 0, 0, base + 32, 0, 0, 0, None) == -1 and b"misaligned" in L.g2048_last_error()
+    args = [base, 0, base, base, base, 0, base, base, 100, 200, 0, 0, base, base, base, base, base, base, None, None]
+    assert L.g2048_minibatch_gather(*args) == -1 and b"without replacement" in L.g2048_last_error()          # batch > n
+    args[9] = 0
+    assert L.g2048_minibatch_gather(*args) == 0                                                               # batch = 0
+    args[9], args[1] = 10, 3
+    assert L.g2048_minibatch_gather(*args) == -1 and b"dtype" in L.g2048_last_error()
+    assert L.g2048_step(base, base, base, base, base, base, 0, 0, 0, 8, 3 << 8, None) == -1 and b"tune 3" in L.g2048_last_error()
+    assert L.g2048_sort_selftest(base, base, 1, -32, None) == -1                                              # the pair network is gone
+
+
+def test_kernel_sources_have_one_compile_time_switch():
+    """Round 3 left thirty-odd compile-time A/B forks in the kernel sources; the default path is now the only path. What is
+    left: the host-compilability guards of the two headers tests/hostsim includes, and the ONE measurement switch
+    (csrc/g2048_instrument.h). At most 8 preprocessor conditionals in csrc/, none of them in a .hip file."""
+    csrc = os.path.join(PKG, "csrc")
+    found = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc", ".hpp")):
+            lines = [l for l in open(os.path.join(csrc, f)) if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", l)]
+            if lines:
+                found[f] = len(lines)
+    assert sum(found.values()) <= 8, found
+    assert not any(f.endswith(".hip") for f in found), found
+    assert not os.path.exists(os.path.join(csrc, "g2048_beam_lanes.inc"))
+
+
+def test_instrumented_builds_are_refused_by_the_loader(built, tmp_path):
+    """A measurement build (-DG2048_INSTRUMENT=N) overwrites real outputs with clock ticks. It reports itself through
+    g2048_build_flags() and g2048/_lib.py refuses it unless the caller opts in (the timeline tools do)."""
+    import subprocess
+    import sys
+    from g2048 import _build
+    so = str(tmp_path / "libg2048_instr.so")
+    src = [os.path.join(_build.CSRC, f) for f in _build.SOURCES]
+    subprocess.check_call(["hipcc"] + _build.FLAGS + ["-DG2048_INSTRUMENT=2", "-o", so] + src)
+    code = ("import sys; sys.path.insert(0, %r); from g2048 import _lib\n"
+            "try:\n    _lib.lib(); print('LOADED', _lib.lib().g2048_build_flags())\n"
+            "except RuntimeError as e:\n    print('REFUSED', 'instrumented' in str(e))\n" % PKG)
+    env = dict(os.environ, G2048_LIB=so)
+    env.pop("G2048_ALLOW_INSTRUMENTED", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout
+    assert "REFUSED True" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, G2048_ALLOW_INSTRUMENTED="1"), capture_output=True, text=True).stdout
+    assert "LOADED 2" in out, out

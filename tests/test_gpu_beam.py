@@ -197,30 +197,6 @@ def test_ranking_network_sorts(ops):
     assert torch.equal(dk.cpu().to(torch.int64)[:, :48], want)
 
 
-def test_ranking_network_pair_top32(ops):
-    """The lane-resident search's network (top32_of_pair): 64 + 64 keys in two registers, the 32 largest of the 128 come out
-    descending in lanes 0..31 -- full registers, sparse ones (keys only in lanes p < 20 of both halves, as a width-20 level has
-    them), one register empty, pre-sorted inputs."""
-    from g2048 import _lib as L
-    g = torch.Generator().manual_seed(11)
-    n_waves = 512
-    vals = (torch.randperm(1 << 24, generator=g)[: n_waves * 128] + 1).to(torch.int64).reshape(n_waves, 2, 64)
-    a, b = vals[:, 0].clone(), vals[:, 1].clone()
-    sparse = torch.zeros(64, dtype=torch.bool)
-    sparse[:20] = True; sparse[32:52] = True
-    a[10:200] *= sparse; b[10:200] *= sparse             # a width-20 level: lanes p < 20 of both halves
-    a[3] = 0                                            # one register without keys
-    b[4] = 0
-    a[5] = 0; b[5] = 0                                  # no keys at all
-    a[6] = torch.arange(128, 64, -1); b[6] = torch.arange(64, 0, -1)
-    a[7] = torch.arange(1, 65); b[7] = torch.arange(65, 129)
-    a[8, 1:] = 0; b[8] = 0                              # a single key
-    da, db = a.to(torch.int32).to(DEV).contiguous(), b.to(torch.int32).to(DEV).contiguous()
-    L.call(da.device, L.lib().g2048_sort_selftest, da.data_ptr(), db.data_ptr(), n_waves, -32, L.stream_ptr(da.device))
-    want = torch.sort(torch.cat([a, b], dim=1), dim=1, descending=True).values[:, :32]
-    assert torch.equal(da.cpu().to(torch.int64)[:, :32], want)
-
-
 def test_ranking_network_sorts_64_bit_keys(ops):
     """The 64-bit variant (levels whose scores are f64): keys differing only in the high word, only in the low word, above
     2^63 and below 2^31."""
@@ -365,3 +341,50 @@ def test_order_of_the_previous_call_is_only_an_order(ops, oracle):
         call(1, nbytes=need - 4)
     with pytest.raises(RuntimeError, match="history"):
         call(0)
+
+
+def test_beam_history_is_thread_safe_and_only_an_order(ops):
+    """The default (balanced_order=True) block order keeps its state in a BeamHistory -- one per (device, stream) for callers
+    that pass none. Two host threads issuing interleaved calls on ONE stream (sharing that history) and on TWO streams, and a
+    caller-owned history shared by two threads: every result equals the caller-order run; the per-stream registry evicts."""
+    import threading
+    n, calls = 4096, 100
+    roots = [ops.synth_boards(n, seed=600 + k, device=DEV, p_empty=0.3 + 0.05 * k, max_code=9) for k in range(3)]
+    want = {}
+    for k in range(3):
+        for si in (0, 1):
+            a, p, e = ops.beam_get_action(roots[k], 20, 12, seed=9, step_index=si, want_expanded=True, balanced_order=False)
+            want[(k, si)] = (a.clone(), e.clone())
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid, stream, history):
+        try:
+            with torch.cuda.stream(stream):
+                for c in range(calls):
+                    k, si = (c + tid) % 3, c & 1
+                    a, p, e = ops.beam_get_action(roots[k], 20, 12, seed=9, step_index=si, want_expanded=True, history=history)
+                    if c % 10 == 9 or c == calls - 1:
+                        stream.synchronize()
+                        if not (torch.equal(a, want[(k, si)][0]) and torch.equal(e, want[(k, si)][1])):
+                            errors.append((tid, c))
+        except Exception as exc:        # noqa: BLE001
+            errors.append((tid, repr(exc)))
+
+    cur = torch.cuda.current_stream()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    own = ops.BeamHistory(DEV)
+    for streams, hist in (((cur, cur), None), ((s1, s2), None), ((s1, s1), own)):
+        th = [threading.Thread(target=worker, args=(i, streams[i], hist)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        assert not errors, errors
+    assert own.calls > 0 and own.n == n
+    # eviction: many short-lived streams do not pin a buffer each
+    for _ in range(40):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            ops.beam_get_action(roots[0], 20, 12, seed=9, step_index=0)
+        st.synchronize()
+    assert len(ops._BEAM_HIST.items) <= ops._BEAM_HIST.cap

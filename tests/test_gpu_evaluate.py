@@ -209,12 +209,13 @@ def test_play_games_workspace_entry_points(g2048):
         ms = torch.full((n, 8), -1, dtype=torch.int32, device=dev)
         ex = torch.zeros(n, dtype=torch.int64, device=dev)
         al = torch.zeros(n, dtype=torch.uint8, device=dev)
-        return b, s, out, ms, ex, al
+        ac = torch.zeros((n, cap), dtype=torch.uint8, device=dev)      # (the library fills it with 0xFF itself)
+        return b, s, out, ms, ex, al, ac
 
     def args(t):
-        b, s, out, ms, ex, al = t
+        b, s, out, ms, ex, al, ac = t
         return (b.data_ptr(), s.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ms.data_ptr(), ex.data_ptr(),
-                al.data_ptr(), w, d, 512, 1024, cap, L.u64(seed), L.u64(0), n, 0)
+                al.data_ptr(), ac.data_ptr(), w, d, 512, 1024, cap, L.u64(seed), L.u64(0), n, 0)
 
     need = int(L.lib().g2048_play_games_workspace(n))
     assert need >= n * 8 * 64 and int(L.lib().g2048_play_games_workspace(0)) == 0
@@ -230,10 +231,13 @@ def test_play_games_workspace_entry_points(g2048):
         else:
             L.call(dev, L.lib().g2048_play_games, *args(t), L.stream_ptr(dev))
         torch.cuda.synchronize()
-        b, s, out, ms, ex, al = t
-        results.append([x.cpu() for x in (b, s, *out, ms, ex, al)])
+        b, s, out, ms, ex, al, ac = t
+        results.append([x.cpu() for x in (b, s, *out, ms, ex, al, ac)])
     for r in results[1:]:
         assert all(torch.equal(x, y) for x, y in zip(results[0], r))
+    moves, ac = results[0][2], results[0][-1]                       # the action stream: 0..3 up to the game's end, 0xFF after it
+    col = torch.arange(cap)[None, :]
+    assert bool((ac[col < moves[:, None]] <= 3).all()) and bool((ac[col >= moves[:, None]] == 0xFF).all())
     t = fresh()
     small = torch.empty(need - 64, dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError, match="workspace"):
@@ -282,12 +286,70 @@ def test_complete_games_vs_oracle_reference_configuration(g2048):
     import oracle_full_games as T
     n = 96
     with get_context("spawn").Pool(16) as pool:
-        job = pool.map_async(T.oracle_game, range(n), chunksize=1)
-        res = g2048.evaluate_beam_search(n, T.W, T.D, seed=T.SEED, max_moves=T.CAP, game_id_base=0)
+        job = pool.map_async(T.oracle_game_with_history, range(n), chunksize=1)
+        res = g2048.evaluate_beam_search(n, T.W, T.D, seed=T.SEED, max_moves=T.CAP, game_id_base=0, histories="all")
+        plain = g2048.evaluate_beam_search(n, T.W, T.D, seed=T.SEED, max_moves=T.CAP, game_id_base=0)      # no action stream asked for
         ref = job.get(timeout=280)
-    for gid, score, moves, invalid, board in ref:
+    for k in PLAY_KEYS:
+        assert res[k] == plain[k], k
+    assert set(res["games"]) == set(range(n))
+    for gid, score, moves, invalid, board, actions, codes, scores in ref:
         assert res["scores"][gid] == score and res["moves"][gid] == moves and res["invalid_moves"][gid] == invalid, gid
         assert [int(x) for x in res["final_boards"][gid].reshape(-1)] == board, gid
+        # f1, the rest of run_game's result (evaluate_beam_search.py:44-50, :72-75): the move-set the fused kernel recorded and
+        # the per-move histories replayed from it, against the oracle's own record of the same game
+        game = res["games"][gid]
+        assert game["moveset"] == list(actions), gid
+        assert len(game["board_history"]) == moves + 1 == len(game["scores_history"]) == len(game["max_tiles_history"]), gid
+        want = np.where(codes > 0, 1 << codes.astype(np.int64), 0).reshape(moves + 1, 4, 4)
+        assert np.array_equal(np.stack(game["board_history"]), want), gid
+        assert game["scores_history"] == [int(x) for x in scores], gid
+        assert game["max_tiles_history"] == [int(x) for x in want.reshape(moves + 1, 16).max(axis=1)], gid
+        assert game["scores_history"][0] == 0 and game["scores_history"][-1] == score and np.array_equal(game["final_board"], want[-1])
+        assert game["milestones"] == {m: (res["milestones_by_game"][gid].get(m)) for m in MILESTONES}
+
+
+def test_action_stream_does_not_depend_on_helpers_or_tuning(g2048, tmp_path):
+    """The recorded move-sets (and so the replayed histories) are the same with helper wavefronts, without them, with the
+    tuning forced to its extremes and with the counting ranking; the two file formats of the reference are written from them:
+    train.py:140-142 (*_best_moveset_tile_N.txt) and evaluate_beam_search.py:185-196 (game_N_data.json)."""
+    from g2048 import ops, save_moveset, save_game_data
+    from g2048.vec import VecGame2048
+    n, w, d, cap, seed = 80, 20, 8, 900, 777
+    streams = []
+    for kw in (dict(one_phase=True), dict(), dict(tuning=(0, 256, 16, 60)), dict(tuning=(64, 1000000, 1, 200)),
+               dict(tuning=(2048, 0, 1000000, 0)), dict(rank_by_counting=True)):
+        env = VecGame2048(n, device=torch.device("cuda"), seed=seed, id_base=17)
+        r = ops.play_games(env.boards, env.scores, w, d, cap, seed=seed, game_id_base=17, want_actions=True, **kw)
+        streams.append((r["actions"].cpu(), r["moves"].cpu(), env.boards.cpu()))
+    for a, m, b in streams[1:]:
+        assert torch.equal(a, streams[0][0]) and torch.equal(m, streams[0][1]) and torch.equal(b, streams[0][2])
+    a, m = streams[0][0], streams[0][1]
+    col = torch.arange(cap)[None, :]
+    assert bool((a[col < m[:, None]] <= 3).all()) and bool((a[col >= m[:, None]] == 0xFF).all())
+    res = g2048.evaluate_beam_search(n, w, d, seed=seed, max_moves=cap, game_id_base=17, histories="best5")
+    assert sorted(res["games"]) == sorted(res["best_games"])
+    g = res["best_games"][0]
+    game = res["games"][g]
+    assert game["moveset"] == [int(x) for x in a[g, :int(m[g])]]
+    p = save_moveset(game, str(tmp_path / "BeamSearchAgent_best_moveset_tile_%d.txt" % game["highest_tile"]))
+    txt = open(p).read()
+    assert txt == ",".join(str(x) for x in game["moveset"]) and not txt.endswith("\n")
+    js = json.load(open(save_game_data(game, str(tmp_path / ("game_%d_data.json" % (g + 1))))))
+    assert set(js) == {"score", "highest_tile", "moves", "valid_moves", "invalid_moves", "milestones", "board_history",
+                       "max_tiles_history", "scores_history", "final_board"}
+    assert js["moves"] == game["moves"] and len(js["board_history"]) == game["moves"] + 1 and js["final_board"] == js["board_history"][-1]
+    assert set(js["milestones"]) == {str(t) for t in MILESTONES}
+    # a replay of a recorded move-set through the public step API ends in the same board (the reference's move-set files are
+    # exactly such streams: include/g2048.h, g2048_step_many)
+    acts = torch.tensor(game["moveset"], dtype=torch.uint8, device="cuda")[:, None].contiguous()
+    b0, s0 = ops.reset(1, seed, 0, 17 + g, device=torch.device("cuda"))
+    out, fl, _, _, _ = ops.step_many(b0, s0, seed, 0, len(game["moveset"]), 17 + g, actions=acts)
+    assert np.array_equal(ops.unpack(out).cpu().numpy().reshape(4, 4), game["final_board"]) and int(s0.item()) == game["score"]
+    hi = g2048.evaluate_beam_search(n, w, d, seed=seed, max_moves=cap, game_id_base=17, histories="high_tile")
+    assert sorted(hi["games"]) == [i for i, t in enumerate(hi["highest_tiles"]) if t >= 2048]
+    with pytest.raises(ValueError):
+        g2048.evaluate_beam_search(4, 3, 3, max_moves=10, fused=False, histories="all")
 
 
 def test_device_plan_reports_what_a_launch_will_use():

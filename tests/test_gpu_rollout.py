@@ -256,3 +256,130 @@ def test_rollout_torch_sampler_still_available(g2048, oracle):
     pol = TinyTransformerPolicy().to(DEV).eval()
     rc = g2048.RolloutCollector(1024, 16, pol, device=DEV, seed=3, sampler="torch")
     replay_and_check(oracle, rc.collect(), 1024, 16, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# f2: PPOMemory.sample on the device (agents/ppo_agent.py:21-50, :342-354)
+
+def feistel_indices(batch, n, k0, k1):
+    """numpy restatement of csrc/g2048_rollout.hip minibatch_index: four Feistel rounds on 2h bits, walked until below n."""
+    def rnd(x, key):
+        h = (x ^ np.uint32(key)).astype(np.uint32)
+        h ^= h >> np.uint32(16); h = (h * np.uint32(0x7FEB352D)).astype(np.uint32)
+        h ^= h >> np.uint32(15); h = (h * np.uint32(0x846CA68B)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        return h
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    hb = (bits + 1) // 2
+    mask = np.uint32((1 << hb) - 1)
+    keys = [k0, k1, (k0 * 0x9E3779B1 + 1) & 0xFFFFFFFF, (k1 * 0x85EBCA77 + 2) & 0xFFFFFFFF]
+    x = np.arange(batch, dtype=np.uint64)
+    todo = np.ones(batch, dtype=bool)
+    while todo.any():
+        l = ((x[todo] >> np.uint64(hb)).astype(np.uint32)) & mask
+        r = x[todo].astype(np.uint32) & mask
+        for key in keys:
+            l, r = r, l ^ (rnd(r, key) & mask)
+        x[todo] = (l.astype(np.uint64) << np.uint64(hb)) | r.astype(np.uint64)
+        todo = x >= n
+    return x.astype(np.int64)
+
+
+def test_minibatch_sample_is_index_select_of_the_trajectory(g2048, oracle):
+    """RolloutCollector.sample(B): distinct indices, every output equal to index_select of the trajectory buffers at those
+    indices, next-state observations equal to the oracle's normalize_state of the gathered (pre-auto-reset) next boards, the
+    indices equal to the numpy restatement of the keyed permutation -- and no host synchronisation inside."""
+    torch.manual_seed(3)
+    n, T = 1024, 48
+    pol = TinyTransformerPolicy().to(DEV).eval()
+    for shaping in (False, True):
+        rc = g2048.RolloutCollector(n, T, pol, device=DEV, seed=21, id_base=9, shaping=shaping, minibatches=True)
+        with pytest.raises(RuntimeError, match="collect"):
+            rc.sample(8)
+        res = rc.collect()
+        torch.cuda.synchronize()
+        flat = lambda t: t.reshape(T * n, *t.shape[2:])        # noqa: E731
+        calls = {"sync": 0, "item": 0}
+        real_sync, real_item = torch.cuda.synchronize, torch.Tensor.item
+        torch.cuda.synchronize = lambda *a, **k: calls.__setitem__("sync", calls["sync"] + 1) or real_sync(*a, **k)
+        torch.Tensor.item = lambda self: calls.__setitem__("item", calls["item"] + 1) or real_item(self)
+        try:
+            batches = [rc.sample(B, want_indices=True) for B in (64, 4096, 1)]
+        finally:
+            torch.cuda.synchronize, torch.Tensor.item = real_sync, real_item
+        assert calls == {"sync": 0, "item": 0}, "sample() must only enqueue"
+        for call, mb in enumerate(batches):
+            idx = mb["indices"]
+            B = idx.shape[0]
+            assert B == (64, 4096, 1)[call] and int(idx.unique().numel()) == B and int(idx.min()) >= 0 and int(idx.max()) < T * n
+            from oracle import oracle as O
+            k0, k1 = O.rng_keys(21, 9, call)                                   # DOM_MINIBATCH = 9, index = sample() call number
+            assert np.array_equal(idx.cpu().numpy(), feistel_indices(B, T * n, k0, k1))
+            assert torch.equal(mb["states"], flat(res["obs"]).index_select(0, idx)) and mb["states"].dtype == torch.float32
+            assert torch.equal(mb["actions"], flat(res["actions"]).index_select(0, idx).to(torch.int64))
+            assert torch.equal(mb["old_log_probs"], flat(res["log_prob"]).index_select(0, idx))
+            rew = flat(res["shaping"]).index_select(0, idx).float() if shaping else flat(res["rewards"]).index_select(0, idx)
+            assert torch.equal(mb["rewards"], rew)
+            assert torch.equal(mb["dones"], flat(res["dones"]).index_select(0, idx).float())
+            nb = flat(rc.next_boards).index_select(0, idx).cpu().numpy()
+            assert np.array_equal(mb["next_states"].cpu().numpy(), oracle.obs_batch(nb))
+        # the next states are the env's return values BEFORE auto-reset: for a finished env that is the dead (full) board, not the
+        # fresh two-tile episode the trajectory's next observation row shows
+        mb = batches[1]
+        done = mb["dones"].cpu().numpy() > 0
+        after = rc._obs[1:].reshape(T * n, 16).index_select(0, mb["indices"]).float().cpu().numpy()
+        got = mb["next_states"].cpu().numpy()
+        assert np.array_equal(after[~done], got[~done])
+        if done.any():
+            assert ((got[done] > 0).sum(axis=1) == 16).all() and ((after[done] > 0).sum(axis=1) == 2).all()
+        whole = rc.sample(10 * T * n)                                           # larger than the buffer: the whole buffer, once
+        assert whole["actions"].shape[0] == T * n
+        a = rc.sample(32, generator=torch.Generator().manual_seed(5), want_indices=True)       # key taken from a CPU generator
+        assert int(a["indices"].unique().numel()) == 32
+        if shaping:
+            rc.check()
+    with pytest.raises(RuntimeError, match="minibatches"):
+        g2048.RolloutCollector(64, 4, pol, device=DEV).sample(4)
+
+
+def test_minibatch_gather_obs_dtypes_and_f64_rewards(g2048, oracle):
+    """g2048_minibatch_gather on raw arrays: float16 / bfloat16 observations widen exactly, float64 rewards round once."""
+    from g2048 import ops
+    n = 5000
+    boards = ops.synth_boards(n, seed=77, device=DEV)
+    nxt = ops.synth_boards(n, seed=78, device=DEV)
+    acts = ops.synth_actions(n, seed=77, device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    logp = torch.randn(n, generator=g).to(DEV)
+    rew = torch.randn(n, generator=g, dtype=torch.float64).to(DEV) * 1e3
+    flags = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        obs = ops.obs(boards, dtype=dt)
+        mb = ops.minibatch_gather(obs, acts, logp, rew, nxt, flags, 777, seed=5, sample_index=3, want_indices=True)
+        idx = mb["indices"]
+        assert int(idx.unique().numel()) == 777
+        assert torch.equal(mb["states"], obs.index_select(0, idx).float())
+        assert torch.equal(mb["rewards"], rew.index_select(0, idx).float())
+        assert torch.equal(mb["dones"], flags.index_select(0, idx).float())
+        assert np.array_equal(mb["next_states"].cpu().numpy(), oracle.obs_batch(nxt.index_select(0, idx).cpu().numpy()))
+    one = ops.minibatch_gather(obs[:1], acts[:1], logp[:1], rew[:1], nxt[:1], flags[:1], 5, seed=1, sample_index=0, want_indices=True)
+    assert one["indices"].tolist() == [0]
+
+
+def test_collector_reports_a_seen_states_overflow(g2048):
+    """A flag raised in the seen-states table during a run is noticed by the collector itself (every CHECK_EVERY collects, or
+    check()), not only when the table next has to grow."""
+    pol = TinyTransformerPolicy().to(DEV).eval()
+    rc = g2048.RolloutCollector(256, 8, pol, device=DEV, seed=3, shaping=True)
+    rc.CHECK_EVERY = 2
+    rc.collect()
+    rc.seen.overflow.fill_(2)                       # what the spin bound of g2048_seen_insert would leave behind
+    with pytest.raises(RuntimeError, match="overflowed"):
+        rc.collect()
+    rc.seen.overflow.zero_()
+    rc.collect()
+    rc.seen.overflow.fill_(1)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        rc.check()

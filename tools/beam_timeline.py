@@ -1,11 +1,12 @@
 """When and where does each search of a 4096-game beam launch run?
 
 Pass 1 (shipped library):  python3 tools/beam_timeline.py expansions [n]   -> gpurun_out/beam_timeline_exp.npy
-Pass 2 (tools/build_ab.sh timing -DG2048_BEAM_TIMING):
+Pass 2 (tools/build_ab.sh timing -DG2048_INSTRUMENT=1):
     G2048_LIB=build_ab/libg2048_timing.so python3 tools/beam_timeline.py timeline [n]
 The timing build writes, instead of prob / expanded, the wall-clock tick (100 MHz) at which a block started, how long it
 ran and the SIMD (XCC, SE, SH, CU, SIMD of HW_ID) it ran on."""
 import os, sys
+os.environ["G2048_ALLOW_INSTRUMENTED"] = "1"      # this tool reads the clock ticks a -DG2048_INSTRUMENT=1 build writes over real outputs
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -24,6 +24,28 @@ def oracle_game(gid):
     return gid, int(score), moves, invalid, [int(x) for x in b.reshape(-1)]
 
 
+def oracle_game_with_history(gid):
+    """oracle_game plus what evaluate_beam_search.run_game also returns (evaluate_beam_search.py:44-50, :72-75): the action of
+    every move, the board before every move and after the last one (uint8 log2 codes, (moves + 1, 16)) and the scores."""
+    import numpy as np
+    from oracle import oracle as O
+    O.set_num_threads(1)
+    k0, k1 = O.rng_keys(SEED, O.DOM_RESET, 0)
+    b = O.env_reset(O.rng_draw(k0, k1, gid, 0), O.rng_draw(k0, k1, gid, 1))
+    score = moves = invalid = 0
+    done = False
+    actions, boards, scores = [], [O.pack(b[None, :])[0].copy()], [0]
+    while not done and moves < CAP:
+        a = O.beam_get_action(b, -1, W, D, seed=SEED, step_index=moves, game_id=gid)["action"]
+        s0, s1 = O.rng_keys(SEED, O.DOM_STEP, moves)
+        b, score, r, done, v, hi = O.env_step(b, score, a, O.rng_draw(s0, s1, gid, 0))
+        invalid += int(not v)
+        moves += 1
+        actions.append(int(a)); boards.append(O.pack(b[None, :])[0].copy()); scores.append(int(score))
+    return (gid, int(score), moves, invalid, [int(x) for x in b.reshape(-1)], bytes(actions), np.stack(boards).astype(np.uint8),
+            np.asarray(scores, dtype=np.int64))
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 32

@@ -1,7 +1,8 @@
-"""The evaluation launch game by game (a -DG2048_PLAY_TIMING build writes, into the milestone record, when a game started / ended,
+"""The evaluation launch game by game (a -DG2048_INSTRUMENT=2 build writes, into the milestone record, when a game started / ended,
 at which move and when it registered for helpers, how many searches its owner ran after that, how many helper results it took
 and how many arrived late):  G2048_LIB=build_ab/libg2048_ptiming.so python3 tools/play_timeline.py [games]"""
 import os, sys
+os.environ["G2048_ALLOW_INSTRUMENTED"] = "1"      # this tool reads the clock ticks a -DG2048_INSTRUMENT=2 build writes over real outputs
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

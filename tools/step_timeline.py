@@ -1,6 +1,7 @@
-"""When and where does each wavefront of a g2048_step launch run? (a -DG2048_STEP_TIMING build writes start tick, end tick (10 ns)
+"""When and where does each wavefront of a g2048_step launch run? (a -DG2048_INSTRUMENT=4 build writes start tick, end tick (10 ns)
 and SIMD of every wavefront over lanes 0..2 of its reward output):  G2048_LIB=build_ab/libg2048_stiming.so python3 tools/step_timeline.py [n]"""
 import os, sys
+os.environ["G2048_ALLOW_INSTRUMENTED"] = "1"      # this tool reads the clock ticks a -DG2048_INSTRUMENT=4 build writes over real outputs
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
