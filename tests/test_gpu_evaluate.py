@@ -332,7 +332,7 @@ def test_action_stream_does_not_depend_on_helpers_or_tuning(g2048, tmp_path):
     g = res["best_games"][0]
     game = res["games"][g]
     assert game["moveset"] == [int(x) for x in a[g, :int(m[g])]]
-    p = save_moveset(game, str(tmp_path / "BeamSearchAgent_best_moveset_tile_%d.txt" % game["highest_tile"]))
+    p = save_moveset(game, str(tmp_path / ("BeamSearchAgent_best_moveset_tile_%d.txt" % game["highest_tile"])))
     txt = open(p).read()
     assert txt == ",".join(str(x) for x in game["moveset"]) and not txt.endswith("\n")
     js = json.load(open(save_game_data(game, str(tmp_path / ("game_%d_data.json" % (g + 1))))))

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 TAG=${1:-r4}
 cd $ROOT
-timeout -k 10 1500 python3 -m pytest tests -x -q -m gpu -s > $OUT/${TAG}_pytest_gpu.log 2>&1 || { tail -60 $OUT/${TAG}_pytest_gpu.log; exit 1; }
+timeout -k 10 1500 python3 -m pytest tests -q -m gpu -s > $OUT/${TAG}_pytest_gpu.log 2>&1 || { tail -60 $OUT/${TAG}_pytest_gpu.log; exit 1; }
 tail -2 $OUT/${TAG}_pytest_gpu.log; grep "drop-in Game2048Env" $OUT/${TAG}_pytest_gpu.log
 timeout -k 10 300 python3 tools/beam_rate.py 4096 > $OUT/${TAG}_beam_rate.txt 2>&1 && timeout -k 10 300 python3 tools/beam_rate.py 8192 >> $OUT/${TAG}_beam_rate.txt 2>&1
 grep -v amdgpu.ids $OUT/${TAG}_beam_rate.txt
