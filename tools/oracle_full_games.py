@@ -47,29 +47,40 @@ def oracle_game_with_history(gid):
 
 
 if __name__ == "__main__":
+    import numpy as np
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     t0 = time.time()
     with get_context("spawn").Pool(procs) as pool:
-        job = pool.map_async(oracle_game, range(BASE, BASE + n), chunksize=1)
+        job = pool.map_async(oracle_game_with_history, range(BASE, BASE + n), chunksize=1)
         import torch
         import __graft_entry__ as ge
         ge.import_package()
         import g2048
-        res = g2048.evaluate_beam_search(n, W, D, seed=SEED, max_moves=CAP, game_id_base=BASE)
-        print("GPU: %d games, %d moves, %.3f s" % (n, res["total_moves"], res["elapsed_s"]), flush=True)
+        res = g2048.evaluate_beam_search(n, W, D, seed=SEED, max_moves=CAP, game_id_base=BASE, histories="all")
+        print("GPU: %d games, %d moves, %.3f s (action stream recorded, every game replayed into its histories)"
+              % (n, res["total_moves"], res["elapsed_s"]), flush=True)
         while not job.ready():
             job.wait(30)
             print("  oracle still playing, %.0f s" % (time.time() - t0), flush=True)
         ref = job.get()
-    bad = 0
-    for gid, score, moves, invalid, board in ref:
+    bad = bad_hist = 0
+    for gid, score, moves, invalid, board, actions, codes, scores in ref:
         g = gid - BASE
         ok = (res["scores"][g] == score and res["moves"][g] == moves and res["invalid_moves"][g] == invalid and
               [int(x) for x in res["final_boards"][g].reshape(-1)] == board)
         bad += not ok
         if not ok:
             print("MISMATCH game", gid, (res["scores"][g], res["moves"][g]), (score, moves))
-    print("oracle: %d games in %.0f s on %d processes; mismatching games: %d; capped games %d; moves %d" % (
-        n, time.time() - t0, procs, bad, sum(1 for r in ref if r[2] >= CAP), sum(r[2] for r in ref)))
-    sys.exit(1 if bad else 0)
+        # f1: the move-set the fused kernel recorded and the histories replayed from it (evaluate_beam_search.py:44-50, :72-75)
+        game = res["games"][g]
+        want = np.where(codes > 0, 1 << codes.astype(np.int64), 0).reshape(moves + 1, 4, 4)
+        okh = (game["moveset"] == list(actions) and game["scores_history"] == [int(x) for x in scores] and
+               np.array_equal(np.stack(game["board_history"]), want) and
+               game["max_tiles_history"] == [int(x) for x in want.reshape(moves + 1, 16).max(axis=1)])
+        bad_hist += not okh
+        if not okh:
+            print("HISTORY MISMATCH game", gid)
+    print("oracle: %d games in %.0f s on %d processes; mismatching games: %d; games whose move-set or replayed histories differ: %d; "
+          "capped games %d; moves %d" % (n, time.time() - t0, procs, bad, bad_hist, sum(1 for r in ref if r[2] >= CAP), sum(r[2] for r in ref)))
+    sys.exit(1 if (bad or bad_hist) else 0)
