@@ -69,4 +69,4 @@ for epoch in range(a.epochs):
     opt.zero_grad(); loss.backward(); opt.step()
 net.eval()
 rc.check()
-print("update on %d sampled transitions (of %d): loss %.4f after %d epochs" % (mb["actions"].shape[0], a.envs * a.steps, float(loss), a.epochs))
+print("update on %d sampled transitions (of %d): loss %.4f after %d epochs" % (mb["actions"].shape[0], a.envs * a.steps, loss.item(), a.epochs))

@@ -367,3 +367,36 @@ def test_device_plan_reports_what_a_launch_will_use():
     big = ops.device_plan(20, p["beam_resident_blocks"] + 1)
     assert not big["beam_issue_priority"]
     assert ops.device_plan(128, 64)["play_resident_blocks_per_cu"] <= p["play_resident_blocks_per_cu"]
+
+
+def test_replay_of_every_game_at_full_size(g2048):
+    """BASELINE config 3's size: 4096 complete games (w=20, d=30), the action stream of ALL of them replayed on the device.
+    Size-independent properties: entry moves[g] of a game's replayed history is the board / score the fused kernel ended with,
+    the flags byte of its last move says done unless the game hit the cap, scores never decrease, the tile sum grows by the
+    spawned 2 or 4 exactly on valid moves, and the counts of valid / invalid flags equal the kernel's counters."""
+    from g2048 import ops, _lib as L
+    from g2048.vec import VecGame2048
+    n, cap, seed = 4096, 5000, 2025
+    env = VecGame2048(n, device=torch.device("cuda"), seed=seed)
+    b0 = env.boards.clone()
+    r = ops.play_games(env.boards, env.scores, 20, 30, cap, seed=seed, want_actions=True)
+    moves = r["moves"]
+    bh, sh, fh = ops.replay_games(b0, r["actions"], moves, seed)
+    idx = moves.to(torch.int64)
+    rows = torch.arange(n, device=bh.device)
+    assert torch.equal(bh[rows, idx], env.boards) and torch.equal(sh[rows, idx], env.scores)
+    last = fh[rows, (idx - 1).clamp(min=0)]
+    done = (last & L.FLAG_DONE).bool()
+    assert torch.equal(done, r["alive"] == 0)
+    t = torch.arange(fh.shape[1], device=bh.device)[None, :]
+    live = t < idx[:, None]
+    valid = ((fh & L.FLAG_VALID) != 0) & live
+    assert torch.equal(valid.sum(dim=1).to(torch.int32), r["valid_moves"])
+    assert torch.equal((live & ~valid).sum(dim=1).to(torch.int32), r["invalid_moves"])
+    assert bool((sh[:, 1:] >= sh[:, :-1])[live[:, :-1]].all())
+    tiles = torch.where(bh > 0, torch.ones_like(bh, dtype=torch.int32) << bh.to(torch.int32), torch.zeros_like(bh, dtype=torch.int32)).sum(dim=2)
+    diff = (tiles[:, 1:] - tiles[:, :-1])[:, :fh.shape[1] - 1]
+    v = valid[:, :fh.shape[1] - 1]
+    lv = live[:, :fh.shape[1] - 1]
+    assert bool(((diff == 2) | (diff == 4))[v].all()) and bool((diff == 0)[lv & ~v].all())
+    assert int(r["alive"].sum()) > 0 and int((moves == cap).sum()) >= int(r["alive"].sum())

@@ -383,3 +383,27 @@ def test_collector_reports_a_seen_states_overflow(g2048):
     rc.seen.overflow.fill_(1)
     with pytest.raises(RuntimeError, match="overflowed"):
         rc.check()
+
+
+def test_minibatch_at_config4_size(g2048):
+    """BASELINE config 4's buffer (65,536 envs x 128 steps = 8,388,608 transitions): a 1 Mi-sample minibatch has distinct indices
+    that cover the range evenly (a permutation prefix, not a clustered walk), equals index_select of the trajectory, and two
+    consecutive sample() calls draw different permutations."""
+    class Uniform(nn.Module):
+        def forward(self, x):
+            return torch.full((x.shape[0], 4), 0.25, device=x.device)
+    n, T = 65536, 128
+    rc = g2048.RolloutCollector(n, T, Uniform(), device=DEV, seed=8, minibatches=True)
+    res = rc.collect()
+    B = 1 << 20
+    a, b = rc.sample(B, want_indices=True), rc.sample(B, want_indices=True)
+    for mb in (a, b):
+        idx = mb["indices"]
+        assert int(idx.unique().numel()) == B and int(idx.max()) < n * T
+        hist = torch.bincount(idx // (n * T // 64), minlength=64).float()
+        assert float(hist.min()) > 0.9 * B / 64 and float(hist.max()) < 1.1 * B / 64
+        assert torch.equal(mb["states"], res["obs"].reshape(n * T, 16).index_select(0, idx))
+        assert torch.equal(mb["actions"], res["actions"].reshape(n * T).index_select(0, idx).to(torch.int64))
+        assert torch.equal(mb["rewards"], res["rewards"].reshape(n * T).index_select(0, idx))
+    assert not torch.equal(a["indices"], b["indices"])
+    assert int(torch.isin(a["indices"][:4096], b["indices"][:4096]).sum()) < 64
