@@ -143,30 +143,8 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
 // already lives in HBM. Sample j of the batch is transition P(j), P a keyed bijection of 0 .. n-1: a four-round Feistel
 // network on 2h bits (2^2h >= n) walked until it lands below n -- cycle walking; the walk ends because P permutes the 2^2h
 // values and j itself is below n --, so the batch is a sample WITHOUT replacement whatever its size, with no table, no sort and
-// no host round trip. Four lanes per sample (one board row = one float4 of each observation per lane).
-__host__ __device__ inline uint32_t minibatch_round(uint32_t x, uint32_t key)
-{
-    uint32_t h = x ^ key;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    return h;
-}
-
-__host__ __device__ inline uint64_t minibatch_index(uint64_t j, uint64_t n, uint32_t half_bits, uint32_t k0, uint32_t k1)
-{
-    const uint32_t mask = half_bits >= 32u ? 0xffffffffu : (1u << half_bits) - 1u;
-    uint64_t x = j;
-    do {
-        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
-        uint32_t t;
-        t = l ^ (minibatch_round(r, k0) & mask); l = r; r = t;
-        t = l ^ (minibatch_round(r, k1) & mask); l = r; r = t;
-        t = l ^ (minibatch_round(r, k0 * 0x9E3779B1u + 1u) & mask); l = r; r = t;
-        t = l ^ (minibatch_round(r, k1 * 0x85EBCA77u + 2u) & mask); l = r; r = t;
-        x = ((uint64_t)l << half_bits) | r;
-    } while (x >= n);
-    return x;
-}
-
+// no host round trip (minibatch_index: g2048_rng.h, where tests/hostsim checks on the CPU that it is a bijection for every n).
+// Four lanes per sample (one board row = one float4 of each observation per lane).
 template <int OBS_KIND, bool REWARD_F64>
 __global__ __launch_bounds__(256) void minibatch_kernel(const void *__restrict__ obs, const uint8_t *__restrict__ actions,
                                                        const float *__restrict__ logp, const void *__restrict__ rewards,
@@ -485,9 +463,7 @@ int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *ac
         !aligned(log_probs, 4) || !aligned(rewards, rewards_f64 ? 8 : 4) || !aligned(actions_out, 8) || !aligned(old_log_probs_out, 4) ||
         !aligned(rewards_out, 4) || !aligned(dones_out, 4) || (indices_out_or_null && !aligned(indices_out_or_null, 8)))
         return fail(G2048_ERR_ARG, "g2048_minibatch_gather: misaligned array");
-    uint32_t bits = 1;
-    while (bits < 64u && ((uint64_t)1 << bits) < (uint64_t)n_transitions) ++bits;
-    const uint32_t half_bits = (bits + 1u) / 2u;
+    const uint32_t half_bits = minibatch_half_bits((uint64_t)n_transitions);
     const Keys k = rng_keys(seed, DOM_MINIBATCH, sample_index);
     if (batch > ((size_t)1 << 36)) return fail(G2048_ERR_ARG, "g2048_minibatch_gather: batch too large for one launch");
     const dim3 grid((unsigned)((batch * 4u + 255u) / 256u));

@@ -154,4 +154,11 @@ void hs_transpose(const uint8_t *in, uint8_t *out, uint8_t *rot, size_t n)
     for (size_t i = 0; i < n; ++i) { st(out + 16 * i, transpose(ld(in + 16 * i))); st(rot + 16 * i, rot180(ld(in + 16 * i))); }
 }
 
+// the keyed bijection behind g2048_minibatch_gather (g2048_rng.h): indices of samples 0 .. batch-1 out of n
+void hs_minibatch_indices(uint64_t n, uint64_t batch, uint32_t k0, uint32_t k1, uint64_t *out)
+{
+    const uint32_t hb = minibatch_half_bits(n);
+    for (uint64_t j = 0; j < batch; ++j) out[j] = minibatch_index(j, n, hb, k0, k1);
+}
+
 }  // extern "C"

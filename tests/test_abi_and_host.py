@@ -249,3 +249,39 @@ def test_instrumented_builds_are_refused_by_the_loader(built, tmp_path):
     assert "REFUSED True" in out, out
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, G2048_ALLOW_INSTRUMENTED="1"), capture_output=True, text=True).stdout
     assert "LOADED 2" in out, out
+
+
+def test_evaluation_result_objects_without_a_device(tmp_path):
+    """Host logic of g2048/evaluate.py on a hand-made per-game table: the result dict's keys (both reference drivers'), the
+    stable top-5 order, which games `histories=` selects, and the two per-game file formats (train.py:140-142,
+    evaluate_beam_search.py:185-196)."""
+    from g2048 import evaluate as E
+    n = 7
+    table = np.zeros((n, E.TABLE_COLUMNS), dtype=np.int64)
+    table[:, 0] = [100, 900, 900, 50, 3000, 10, 700]            # scores (a tie: stable order keeps game 1 before game 2)
+    table[:, 1] = [10, 40, 41, 5, 120, 3, 30]                   # moves
+    table[:, 2] = table[:, 1] - 1; table[:, 3] = 1
+    table[:, 6:14] = -1
+    table[4, 6:12] = [5, 9, 20, 40, 70, 110]                    # game 4 reached 64 .. 2048
+    table[:, 14:30] = 2; table[4, 14] = 2048; table[1, 14] = 1024
+    res = E.results_from_table(table, 0.5, 20, 30, 7, 5000)
+    assert res["best_games"] == [4, 1, 2, 6, 0] and res["best_game_idx"] == 4 and res["best_score"] == 3000
+    assert res["highest_tiles"][4] == 2048 and res["milestones"][2048] == [110] and res["milestones"][4096] == []
+    assert res["milestones_by_game"][4] == {64: 5, 128: 9, 256: 20, 512: 40, 1024: 70, 2048: 110} and res["milestones_by_game"][0] == {}
+    assert E._select_games(res, "best5") == [4, 1, 2, 6, 0] and E._select_games(res, "high_tile") == [4]
+    assert E._select_games(res, "all") == list(range(n)) and E._select_games(res, (3, 1)) == [3, 1]
+    for bad in ("worst", [7], [-1]):
+        with pytest.raises(ValueError):
+            E._select_games(res, bad)
+    game = {"score": 3000, "highest_tile": 2048, "moves": 3, "valid_moves": 2, "invalid_moves": 1,
+            "milestones": {m: res["milestones_by_game"][4].get(m) for m in E.MILESTONES},
+            "board_history": [np.full((4, 4), k, np.int32) for k in range(4)], "max_tiles_history": [0, 1, 2, 3],
+            "scores_history": [0, 4, 4, 12], "final_board": np.full((4, 4), 3, np.int32), "moveset": [3, 3, 1]}
+    assert open(E.save_moveset(game, str(tmp_path / "m.txt"))).read() == "3,3,1"
+    assert open(E.save_moveset([0, 2], str(tmp_path / "m2.txt"))).read() == "0,2"
+    js = json.load(open(E.save_game_data(game, str(tmp_path / "g.json"))))
+    assert js["board_history"][2] == [[2] * 4] * 4 and js["final_board"] == [[3] * 4] * 4 and js["milestones"]["8192"] is None
+    assert js["milestones"]["2048"] == 110 and "moveset" not in js
+    p = E.save_overall_results(res, str(tmp_path / "overall_results.json"))
+    assert set(json.load(open(p))) == {"scores", "highest_tiles", "moves", "valid_moves", "invalid_moves", "milestones", "best_games",
+                                       "parameters"}

@@ -76,3 +76,26 @@ def test_masks_evals_and_moves_equal_oracle(oracle, b):
         o = np.empty(1, np.float64)
         HS.hs_eval(p(b), 1, p(np.array([ph], np.uint8)), p(o, C.c_double), C.c_size_t(1))
         assert o[0] == oracle.full_eval(t, ph)
+
+
+@settings(max_examples=60, deadline=None)
+@given(n=st.one_of(st.integers(1, 70), st.integers(1, 5000), st.sampled_from([1 << 10, (1 << 10) + 1, 65535, 65536, 65537, 1 << 17, 300007])),
+       k0=st.integers(0, 2**32 - 1), k1=st.integers(0, 2**32 - 1))
+def test_minibatch_permutation_is_a_bijection_for_every_n(n, k0, k1):
+    """PPOMemory.sample draws WITHOUT replacement (agents/ppo_agent.py:25): the Feistel network walked into range
+    (csrc/g2048_rng.h, the definition the kernel compiles) maps 0 .. n-1 onto 0 .. n-1 one to one for any n and any key,
+    so every prefix of it -- a minibatch -- has distinct indices."""
+    out = np.empty(n, np.uint64)
+    HS.hs_minibatch_indices(C.c_uint64(n), C.c_uint64(n), C.c_uint32(k0), C.c_uint32(k1), p(out, C.c_uint64))
+    assert np.array_equal(np.sort(out), np.arange(n, dtype=np.uint64))
+
+
+def test_minibatch_permutation_spreads_and_depends_on_the_key():
+    n, B = 8388608, 65536                       # config 4's buffer, a 64 Ki-sample minibatch
+    a, b = np.empty(B, np.uint64), np.empty(B, np.uint64)
+    HS.hs_minibatch_indices(C.c_uint64(n), C.c_uint64(B), C.c_uint32(1), C.c_uint32(2), p(a, C.c_uint64))
+    HS.hs_minibatch_indices(C.c_uint64(n), C.c_uint64(B), C.c_uint32(3), C.c_uint32(2), p(b, C.c_uint64))
+    assert len(np.unique(a)) == B and len(np.unique(b)) == B and a.max() < n
+    hist = np.bincount((a // (n // 64)).astype(np.int64), minlength=64)
+    assert hist.min() > 0.8 * B / 64 and hist.max() < 1.2 * B / 64
+    assert len(np.intersect1d(a, b)) < 4 * B * B / n + 200          # two keys: about B^2 / n common indices, as independent draws would have
