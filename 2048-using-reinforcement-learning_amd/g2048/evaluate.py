@@ -257,6 +257,8 @@ def evaluate_beam_search_sharded(num_games=4096, beam_width=20, search_depth=30,
     it with no communication, and one all-gather of the per-game table (30 int64 per game) at the end gives every rank the
     result of the whole evaluation -- identical to evaluate_beam_search(num_games) on one GPU. elapsed_s = slowest rank."""
     from . import dist as gdist
+    if kw.get("histories") is not None:
+        raise ValueError("evaluate_beam_search_sharded gathers the per-game table only; replay histories per rank with evaluate_beam_search")
     w, r, lr = gdist.world()
     dev = torch.device(device) if device is not None else torch.device("cuda", lr)
     lo, hi = gdist.shard(num_games, r, w)

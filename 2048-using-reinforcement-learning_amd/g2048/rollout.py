@@ -60,6 +60,8 @@ class RolloutCollector:
         self.minibatches = bool(minibatches) or self.shaping     # sample() needs the next states before auto-reset, as shaping does
         self._samples = 0           # sample() calls so far (RNG index of the minibatch permutation)
         self._seed = int(seed)
+        self._filled = False        # a collect() has filled the trajectory buffers
+        self._collects_since_check = 0
         self.sampler = sampler
         self.env = VecGame2048(self.n, device=self.device, seed=seed, id_base=id_base, auto_reset=True)
         d, T, n = self.device, self.T, self.n
@@ -199,7 +201,7 @@ class RolloutCollector:
             T, n = self.T, self.n
             ops.remember_shaping(self.seen, self.next_boards.view(T * n, 16), self.state_maxcode.view(T * n),
                                  self.flags.view(T * n), self.rewards64.view(T * n), out=self.shaped.view(T * n))
-            self._collects_since_check = getattr(self, "_collects_since_check", 0) + 1
+            self._collects_since_check += 1
             if self._collects_since_check >= self.CHECK_EVERY:     # the table's overflow flag: one host sync every so often
                 self.check()
         self._filled = True
@@ -231,7 +233,7 @@ class RolloutCollector:
         of sample() calls so far); generator: a CPU torch.Generator to take the key from instead."""
         if not self.minibatches:
             raise RuntimeError("RolloutCollector.sample needs minibatches=True (or shaping=True): the next states are not recorded")
-        if not getattr(self, "_filled", False):
+        if not self._filled:
             raise RuntimeError("RolloutCollector.sample: collect() first")
         seed = self._seed
         if generator is not None:
