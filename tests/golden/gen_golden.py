@@ -652,6 +652,60 @@ def gen_simulate_sampled():
                         done=done, count=count, seed=np.uint64(SEED), step_index=np.uint64(3))
 
 
+def gen_games():
+    """Complete games in the shape of the reference's run_game (evaluate_beam_search.py:29-98) and train.py's episode loop
+    (:48-75), played by the REAL Game2048Env + BeamSearchAgent with the product's draw schedule: reset (SEED, RESET, 0, game id,
+    0/1); move t: the search's draws (SEED, BEAM, t, game id, j) in the order the agent consumes them, the env's spawn (SEED,
+    STEP, t, game id, 0). Recorded per game: what run_game returns beyond the counters -- board_history, scores_history,
+    max_tiles_history, milestones -- and train.py's moveset. Small beams keep the reference's Python search affordable (three games at
+    width 3 / depth 4 and four greedy ones run to their end or the 5000-move cap, three at width 4 / depth 5 are cut at 250 moves); two
+    games at the evaluation configuration (width 20, depth 30) are cut at 30 moves."""
+    env = Game2048Env()
+    out, meta = {}, []
+    t0 = time.time()
+    configs = [(3, 4, 5000, 3), (1, 1, 5000, 4), (4, 5, 250, 3), (20, 30, 30, 2)]          # width, depth, move cap, games
+    gid = 7000
+    k = 0
+    for w, d, cap, ngames in configs:
+        agent = BeamSearchAgent(beam_width=w, search_depth=d)
+        for _ in range(ngames):
+            STREAM.source = list_source([hashed(O.DOM_RESET, 0, gid, 0), hashed(O.DOM_RESET, 0, gid, 1)])
+            state = env.reset()
+            done, moves, valid_n, invalid_n = False, 0, 0, 0
+            milestones = {m: -1 for m in (64, 128, 256, 512, 1024, 2048, 4096, 8192)}
+            boards, scores, maxt, moveset = [codes_of(state)], [0], [int(np.max(state))], []
+            while not done and moves < cap:                               # evaluate_beam_search.py:52
+                k0, k1 = O.rng_keys(SEED, O.DOM_BEAM, moves)
+                ctr = [0]
+
+                def src():
+                    h = O.rng_draw(k0, k1, gid, ctr[0])
+                    ctr[0] += 1
+                    return h
+                STREAM.source = src
+                action, _ = agent.get_action(state)                       # :54 (no caller mask)
+                STREAM.source = list_source([hashed(O.DOM_STEP, moves, gid)])
+                state, reward, done, info = env.step(action)              # :58
+                mt = int(np.max(state))
+                for m in milestones:                                      # :60-64
+                    if mt >= m and milestones[m] < 0:
+                        milestones[m] = moves
+                valid_n += int(bool(info["valid_move"])); invalid_n += int(not info["valid_move"])
+                boards.append(codes_of(state)); maxt.append(mt); scores.append(int(info["score"])); moveset.append(int(action))
+                moves += 1
+            out["g%d_boards" % k] = np.array(boards, np.uint8)
+            out["g%d_scores" % k] = np.array(scores, np.int64)
+            out["g%d_max_tiles" % k] = np.array(maxt, np.int64)
+            out["g%d_moveset" % k] = np.array(moveset, np.uint8)
+            out["g%d_milestones" % k] = np.array([milestones[m] for m in (64, 128, 256, 512, 1024, 2048, 4096, 8192)], np.int32)
+            meta.append((w, d, cap, gid, moves, valid_n, invalid_n, int(info["score"]), int(done)))
+            print("  game", k, (w, d), "moves", moves, "score", int(info["score"]), "max", maxt[-1], "done", done, "%.1fs" % (time.time() - t0))
+            gid += 1; k += 1
+    out["meta"] = np.array(meta, np.int64)      # width, depth, cap, game id, moves, valid, invalid, score, done
+    out["seed"] = np.uint64(SEED)
+    np.savez_compressed(os.path.join(HERE, "games.npz"), **out)
+
+
 def gen_pattern():
     """Game2048Env._evaluate_pattern (environment/game_2048.py:313-339; nobody in the reference calls it) on the boards of
     eval_scores.npz."""
@@ -702,8 +756,8 @@ def gen_checkpoint():
 def main():
     if "--only" in sys.argv:
         what = sys.argv[sys.argv.index("--only") + 1]
-        if what in ("pattern", "checkpoint"):
-            {"pattern": gen_pattern, "checkpoint": gen_checkpoint}[what]()
+        if what in ("pattern", "checkpoint", "games"):
+            {"pattern": gen_pattern, "checkpoint": gen_checkpoint, "games": gen_games}[what]()
             return
         if what == "step_noop":
             rng = np.random.default_rng(1)
@@ -773,6 +827,7 @@ def main():
                                   random_code_boards(rng2, 300, 0.6, 17)]).astype(np.uint8))
     gen_pattern()
     gen_checkpoint()
+    gen_games()
     print("done in %.1fs" % (time.time() - t0))
 
 

@@ -400,3 +400,29 @@ def test_replay_of_every_game_at_full_size(g2048):
     lv = live[:, :fh.shape[1] - 1]
     assert bool(((diff == 2) | (diff == 4))[v].all()) and bool((diff == 0)[lv & ~v].all())
     assert int(r["alive"].sum()) > 0 and int((moves == cap).sum()) >= int(r["alive"].sum())
+
+
+def test_complete_games_of_the_real_reference(g2048):
+    """tests/golden/games.npz (the REAL reference's env + agent in run_game's loop, evaluate_beam_search.py:29-98): the fused
+    evaluation plays the same games -- counters, final boards -- and the recorded move-sets and replayed histories are the
+    reference's moveset / board_history / scores_history / max_tiles_history / milestones, move by move."""
+    from conftest import load_golden, tiles_of
+    g = load_golden("games.npz")
+    seed, meta = int(g["seed"]), g["meta"]
+    k = 0
+    while k < meta.shape[0]:
+        w, d, cap, gid0 = (int(x) for x in meta[k, :4])
+        group = [j for j in range(meta.shape[0]) if tuple(meta[j, :3]) == tuple(meta[k, :3])]
+        assert [int(meta[j, 3]) for j in group] == list(range(gid0, gid0 + len(group)))
+        res = g2048.evaluate_beam_search(len(group), w, d, seed=seed, max_moves=cap, game_id_base=gid0, histories="all")
+        for i, j in enumerate(group):
+            _, _, _, gid, moves, valid_n, invalid_n, score, done = (int(x) for x in meta[j])
+            assert (res["moves"][i], res["valid_moves"][i], res["invalid_moves"][i], res["scores"][i]) == (moves, valid_n, invalid_n, score), j
+            game = res["games"][i]
+            assert game["moveset"] == g["g%d_moveset" % j].tolist(), j
+            assert np.array_equal(np.stack(game["board_history"]).reshape(moves + 1, 16), tiles_of(g["g%d_boards" % j])), j
+            assert game["scores_history"] == g["g%d_scores" % j].tolist() and game["max_tiles_history"] == g["g%d_max_tiles" % j].tolist(), j
+            want_ms = {m: (int(v) if v >= 0 else None) for m, v in zip(MILESTONES, g["g%d_milestones" % j])}
+            assert game["milestones"] == want_ms, j
+            assert not done or res["final_boards"][i].min() > 0                   # a finished game ends on a full board
+        k = group[-1] + 1

@@ -246,3 +246,35 @@ def test_step_out_of_range_actions_golden(oracle):
     assert np.array_equal(bo, g["board_out"]) and np.array_equal(so.astype(np.int32), g["score_out"])
     assert np.array_equal(ro, g["reward"], equal_nan=True)
     assert np.array_equal(fo & 1, g["done"]) and not ((fo >> 1) & 1).any() and int(g["done"].sum()) >= 20
+
+
+MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)
+
+
+def test_complete_games_golden(oracle):
+    """tests/golden/games.npz: twelve games played by the REAL Game2048Env + BeamSearchAgent in the shape of the reference's
+    run_game (evaluate_beam_search.py:29-98): complete ones (done, and one stuck at the 5000-move cap), cut ones, two at the
+    evaluation configuration. The oracle playing the same games decides every move the same way and passes through the same
+    boards, scores, max tiles and milestones -- the pin behind the move-sets / histories the GPU path records and replays."""
+    g = load_golden("games.npz")
+    seed = int(g["seed"])
+    assert g["meta"].shape[0] == 12 and int(g["meta"][:, 8].sum()) >= 6 and int((g["meta"][:, 4] == 5000).sum()) == 1
+    for k, (w, d, cap, gid, moves, valid_n, invalid_n, score, done) in enumerate(g["meta"].tolist()):
+        if moves > 1500:                  # (the capped game: its first 1500 moves are enough for the CPU suite; the GPU test plays all 5000)
+            moves = 1500
+        k0, k1 = oracle.rng_keys(seed, oracle.DOM_RESET, 0)
+        b = oracle.env_reset(oracle.rng_draw(k0, k1, gid, 0), oracle.rng_draw(k0, k1, gid, 1))
+        assert np.array_equal(b, tiles_of(g["g%d_boards" % k][0]))
+        sc, ms = 0, {m: -1 for m in MILESTONES}
+        for t in range(moves):
+            a = oracle.beam_get_action(b, -1, w, d, seed=seed, step_index=t, game_id=gid)["action"]
+            assert a == g["g%d_moveset" % k][t], (k, t)
+            s0, s1 = oracle.rng_keys(seed, oracle.DOM_STEP, t)
+            b, sc, r, dn, v, hi = oracle.env_step(b, sc, a, oracle.rng_draw(s0, s1, gid, 0))
+            assert np.array_equal(b, tiles_of(g["g%d_boards" % k][t + 1])), (k, t)
+            assert sc == g["g%d_scores" % k][t + 1] and b.max() == g["g%d_max_tiles" % k][t + 1]
+            for m in MILESTONES:
+                if b.max() >= m and ms[m] < 0:
+                    ms[m] = t
+        if moves == g["meta"][k, 4]:
+            assert [ms[m] for m in MILESTONES] == g["g%d_milestones" % k].tolist() and bool(dn) == bool(done) and sc == score
