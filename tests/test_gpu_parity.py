@@ -339,6 +339,22 @@ def test_drop_in_env_single_step_rate(ops):
     assert steps / dt > 1000
 
 
+def test_drop_in_env_replays_a_reference_episode(ops):
+    """Config 1 through the drop-in class against the REAL reference: episode 0 of tests/golden/episodes.npz (reset spawns,
+    every state, f64 reward, done, score, valid flag of a complete seeded episode) with both record homes."""
+    from environment.game_2048 import Game2048Env
+    g = load_golden("episodes.npz")
+    for home in ("host", "device"):
+        env = Game2048Env(seed=int(g["seed"]), record=home)
+        assert np.array_equal(env.get_state(), tiles_of(g["ep0_board0"]))
+        for t in range(g["ep0_action"].shape[0]):
+            s, r, d, info = env.step(int(g["ep0_action"][t]))
+            assert np.array_equal(s, tiles_of(g["ep0_board"][t])) and r == g["ep0_reward"][t], (home, t)
+            assert d == bool(g["ep0_done"][t]) and info["score"] == g["ep0_score"][t] and info["valid_move"] == bool(g["ep0_valid"][t])
+            assert info["highest_tile"] == max(tiles_of(g["ep0_board0"]).max(), tiles_of(g["ep0_board"][:t + 1]).max())
+        assert env.game_over and not any(env.get_valid_moves())
+
+
 def test_drop_in_env_one_launch_per_iteration(ops, oracle):
     """Config 1 (train.py:55-75: get_valid_moves + step every iteration): one g2048_env_step launch and one synchronisation per
     iteration whether the 80-byte record lands in pinned host memory or in device memory; get_valid_moves() is a cache read
