@@ -472,6 +472,7 @@ def main():
                                     "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); `value` = mean of three "
                                     "such batches (round 3 reported the best of three: 6.94e10 best / 6.80e10 mean then; rounds 1-2 one batch)",
                           "decisions_per_s": BEAM_GAMES * breps / bsec_mean, "ms_per_batch_decision": bsec_mean / breps * 1e3,
+                          "parents_expanded_per_s_approx": beam_mean / 4.0,     # "parents-expanded/s (= expansions / ~4)"
                           "ms_per_batch_decision_best": bsec / breps * 1e3,
                           "gbs_equivalent_29B": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9,
                           "gbs_equivalent_29B_frac_of_hbm_peak": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
