@@ -166,7 +166,7 @@ def game_histories(results, which, boards0, actions, moves, seed, game_id_base=0
     longest = int(moves.index_select(0, idx).max().item())
     bh, shist, fh = ops.replay_games(boards0.index_select(0, idx).contiguous(),
                                      actions.index_select(0, idx)[:, :max(longest, 1)].contiguous(),
-                                     moves.index_select(0, idx).contiguous(), seed, game_ids=idx + int(game_id_base))
+                                     moves.index_select(0, idx).contiguous(), seed, game_ids=idx + int(game_id_base), longest=longest)
     k, hist = bh.shape[0], bh.shape[1]
     tiles = ops.unpack(bh.view(k * hist, 16)).view(k, hist, 4, 4).cpu().numpy()
     shist, fh = shist.cpu().numpy(), fh.cpu().numpy()

@@ -674,13 +674,14 @@ def play_games(boards, scores, width, depth, max_moves=5000, early_threshold=512
     return out
 
 
-def replay_games(boards0, actions, n_moves, seed, game_ids=None, game_id_base=0, scores0=None):
+def replay_games(boards0, actions, n_moves, seed, game_ids=None, game_id_base=0, scores0=None, longest=None):
     """Recorded games replayed into their per-move histories (g2048_replay_games; reference evaluate_beam_search.py:44-50,
     :72-75: board_history / scores_history / max_tiles_history of run_game). boards0 uint8 (k,16): where each game started;
     actions uint8 (k, stride): its action bytes as `play_games(want_actions=True)` wrote them; n_moves int32 (k,); game_ids
     int64 (k,) = the GLOBAL ids the games were played under (None: game_id_base + row). Returns (boards_hist uint8
     (k, L+1, 16), score_hist int32 (k, L+1), flags_hist uint8 (k, L+1)), L = the longest game; entry t = the state before move
-    t, entry n_moves = the final state; entries past a game's end are zero."""
+    t, entry n_moves = the final state; entries past a game's end are zero. longest: an upper bound of n_moves the caller
+    already knows (e.g. the move cap) -- without it the histories are sized by one read-back of n_moves.max()."""
     L.require_device_tensor(boards0, torch.uint8, (16,), "boards0")
     L.require_device_tensor(actions, torch.uint8, None, "actions")
     L.require_device_tensor(n_moves, torch.int32, None, "n_moves")
@@ -693,7 +694,9 @@ def replay_games(boards0, actions, n_moves, seed, game_ids=None, game_id_base=0,
             raise ValueError("g2048: game_ids must have one id per game")
     if scores0 is not None:
         _require_scores(scores0)
-    longest = min(int(n_moves.max().item()), actions.shape[1]) if k else 0       # (one host sync: the histories are sized by it)
+    if longest is None:
+        longest = int(n_moves.max().item()) if k else 0                          # (one host sync: the histories are sized by it)
+    longest = min(int(longest), actions.shape[1])
     hist = longest + 1
     boards_hist = torch.zeros((k, hist, 16), dtype=torch.uint8, device=dev)
     score_hist = torch.zeros((k, hist), dtype=torch.int32, device=dev)
