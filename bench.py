@@ -457,6 +457,15 @@ def main():
             b1.record()
             torch.cuda.synchronize()
             batches.append((b0.elapsed_time(b1) * 1e-3, int(torch.stack(exps).sum().item())))
+        # a fourth, separate batch with an event between every two calls: the per-call durations (kernel + one launch boundary), whose
+        # median is what a rocprofv3 kernel trace of this command shows for beam_kernel<2> (profiles/r04_bench_kernel_trace_stats.txt)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(breps + 1)]
+        marks[0].record()
+        for w in range(breps):
+            ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w, game_id_base=rank * BEAM_GAMES, want_expanded=True)
+            marks[w + 1].record()
+        torch.cuda.synchronize()
+        per_call_us = sorted(marks[w].elapsed_time(marks[w + 1]) * 1e3 for w in range(breps))
         bsec, total_exp = min(batches)
         beam_mean = sum(x / t for t, x in batches) / len(batches)
         beam_best = total_exp / bsec
@@ -474,6 +483,7 @@ def main():
                           "decisions_per_s": BEAM_GAMES * breps / bsec_mean, "ms_per_batch_decision": bsec_mean / breps * 1e3,
                           "parents_expanded_per_s_approx": beam_mean / 4.0,     # "parents-expanded/s (= expansions / ~4)"
                           "ms_per_batch_decision_best": bsec / breps * 1e3,
+                          "us_per_call_median_of_20_event_pairs": per_call_us[len(per_call_us) // 2], "us_per_call_min": per_call_us[0],
                           "gbs_equivalent_29B": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9,
                           "gbs_equivalent_29B_frac_of_hbm_peak": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
                           "gbs_equivalent_note": "SURVEY 8(d): 29 B per expansion if the beam lived in HBM; the search keeps it in LDS "
