@@ -631,3 +631,41 @@ def test_vec_env_random_playout_equals_steps(ops):
     b2, r2, d2, _ = e2.step()
     assert bool((b1 == b2).all()) and np.array_equal(host(r1), host(r2), equal_nan=True)
 
+
+
+def test_replay_games_equals_the_step_path_on_arbitrary_action_streams(ops, oracle):
+    """g2048_replay_games against the pinned step path on action streams nobody played: 20,000 boards x 160 uniform actions
+    (many invalid moves, finished boards that stay put), ragged lengths, ids with a high word. Entry t of a history = the board
+    g2048_step_many reaches after t steps; the score and flags streams agree; a byte above 3 ends a game's replay; and the
+    first 40 games equal the oracle's env_step move by move."""
+    n, T, seed, base = 20000, 160, 99, (3 << 33) + 17
+    b0, s0 = ops.reset(n, seed, 0, base, device=DEV)
+    acts = torch.stack([ops.synth_actions(n, seed=seed + 1, step_index=t, id_base=base, device=DEV) for t in range(T)])      # (T, n)
+    lens = (torch.arange(n, device=DEV) % (T + 1)).to(torch.int32)                         # 0 .. T moves
+    game_major = acts.t().contiguous()
+    bh, sh, fh = ops.replay_games(b0, game_major, lens, seed, game_id_base=base)
+    assert bh.shape == (n, T + 1, 16)
+    cur, sc = b0.clone(), s0.clone()
+    for t in range(T):
+        at = lens > t                                                                      # games that play move t
+        assert torch.equal(bh[at, t], cur[at]) and torch.equal(sh[at, t], sc[at]), t
+        nxt, _, fl = ops.step(cur, acts[t], sc, seed, t, base, reward_f64=True)
+        assert torch.equal(fh[at, t], fl[at]), t
+        cur = nxt
+        done_here = lens == t + 1
+        assert torch.equal(bh[done_here, t + 1], cur[done_here]) and torch.equal(sh[done_here, t + 1], sc[done_here])
+    # beyond a game's end nothing is written (the wrapper zero-fills)
+    col = torch.arange(T + 1, device=DEV)[None, :]
+    assert bool((bh[col.expand(n, -1) > lens[:, None]] == 0).all())
+    # a byte above 3 ends the replay of that game: same histories as the shortened length
+    cut = game_major.clone(); cut[:, 50] = 0xFF
+    bh2, sh2, _ = ops.replay_games(b0, cut, torch.full((n,), T, dtype=torch.int32, device=DEV), seed, game_id_base=base)
+    bh3, sh3, _ = ops.replay_games(b0, game_major, torch.full((n,), 50, dtype=torch.int32, device=DEV), seed, game_id_base=base, longest=T)
+    assert torch.equal(bh2, bh3) and torch.equal(sh2, sh3)
+    hb, ha = b0.cpu().numpy(), game_major.cpu().numpy()
+    for g in range(40):
+        b, score = oracle.unpack(hb[g:g + 1])[0], 0
+        for t in range(int(lens[g])):
+            k0, k1 = oracle.rng_keys(seed, oracle.DOM_STEP, t)
+            b, score, r, d, v, hi = oracle.env_step(b, score, int(ha[g, t]), oracle.rng_draw(k0, k1, base + g, 0))
+            assert np.array_equal(oracle.unpack(bh[g, t + 1].cpu().numpy()[None, :])[0], b) and int(sh[g, t + 1]) == score, (g, t)
