@@ -723,12 +723,13 @@ def env_step(board, score, record, seed, index, board_id=0, action=0, op=None):
            L.ENV_OP_STEP if op is None else int(op), record.data_ptr(), L.u64(seed), L.u64(index), L.u64(board_id), L.stream_ptr(dev))
 
 
-def minibatch_gather(obs, actions, log_probs, rewards, next_boards, flags, batch, seed, sample_index, want_indices=False):
+def minibatch_gather(obs, actions, log_probs, rewards, next_boards, flags, batch, seed, sample_index, want_indices=False, out=None):
     """PPOMemory.sample + the head of PPOAgent.update (agents/ppo_agent.py:21-50, :342-354) on a device-resident trajectory
     (g2048_minibatch_gather): `batch` distinct transitions drawn and gathered by one launch, no host sync. Inputs are flat over
     the transitions: obs (n,16) float32 / float16 / bfloat16, actions uint8, log_probs float32, rewards float32 or float64,
     next_boards uint8 (n,16) (before any auto-reset), flags uint8. Returns dict(states, actions, old_log_probs, rewards,
-    next_states, dones[, indices])."""
+    next_states, dones[, indices]). out: the dict a previous call of the same batch size returned, to be overwritten (at the
+    reference's batch sizes a call is mostly the host time of allocating six small tensors)."""
     if obs.dtype not in _OBS_KIND:
         raise TypeError("g2048: obs must be float32, float16 or bfloat16")
     L.require_device_tensor(obs, obs.dtype, (16,), "obs")
@@ -743,14 +744,19 @@ def minibatch_gather(obs, actions, log_probs, rewards, next_boards, flags, batch
     if not (actions.shape[0] == log_probs.shape[0] == rewards.shape[0] == next_boards.shape[0] == flags.shape[0] == n):
         raise ValueError("g2048: all trajectory arrays must have one entry per transition")
     batch = min(int(batch), n)                      # PPOMemory.sample: a batch larger than the buffer is the whole buffer
-    out = {"states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
-           "actions": torch.empty(batch, dtype=torch.int64, device=dev),
-           "old_log_probs": torch.empty(batch, dtype=torch.float32, device=dev),
-           "rewards": torch.empty(batch, dtype=torch.float32, device=dev),
-           "next_states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
-           "dones": torch.empty(batch, dtype=torch.float32, device=dev)}
-    if want_indices:
-        out["indices"] = torch.empty(batch, dtype=torch.int64, device=dev)
+    if out is not None:
+        if out["actions"].shape[0] != batch or out["states"].device != dev or (want_indices and "indices" not in out):
+            raise ValueError("g2048: `out` must come from a call with the same batch size, device and want_indices")
+        want_indices = "indices" in out
+    else:
+        out = {"states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
+               "actions": torch.empty(batch, dtype=torch.int64, device=dev),
+               "old_log_probs": torch.empty(batch, dtype=torch.float32, device=dev),
+               "rewards": torch.empty(batch, dtype=torch.float32, device=dev),
+               "next_states": torch.empty((batch, 16), dtype=torch.float32, device=dev),
+               "dones": torch.empty(batch, dtype=torch.float32, device=dev)}
+        if want_indices:
+            out["indices"] = torch.empty(batch, dtype=torch.int64, device=dev)
     L.call(dev, L.lib().g2048_minibatch_gather, obs.data_ptr(), _OBS_KIND[obs.dtype], actions.data_ptr(), log_probs.data_ptr(),
            rewards.data_ptr(), int(rewards.dtype == torch.float64), next_boards.data_ptr(), flags.data_ptr(), n, batch, L.u64(seed),
            L.u64(sample_index), out["states"].data_ptr(), out["actions"].data_ptr(), out["old_log_probs"].data_ptr(),

@@ -223,14 +223,15 @@ class RolloutCollector:
         if self.seen is not None:
             self.seen.assert_ok()
 
-    def sample(self, batch_size, generator=None, want_indices=False):
+    def sample(self, batch_size, generator=None, want_indices=False, out=None):
         """PPOMemory.sample(batch_size) (agents/ppo_agent.py:21-50) over the transitions of the last collect(), as the tensors
         PPOAgent.update builds from it (:342-354): dict(states float32 (B,16) normalized, actions int64 (B,), old_log_probs
         float32 (B,), rewards float32 (B,) -- the shaped reward remember() stores when shaping=True, else the env's --,
         next_states float32 (B,16) normalized (the state the env returned, before any auto-reset), dones float32 (B,)).
         B distinct transitions (without replacement; a batch larger than the buffer is the whole buffer), drawn and gathered
         by ONE launch (g2048_minibatch_gather), no host synchronisation. The draw is keyed by (the collector's seed, the number
-        of sample() calls so far); generator: a CPU torch.Generator to take the key from instead."""
+        of sample() calls so far); generator: a CPU torch.Generator to take the key from instead; out: the dict a previous call
+        of the same batch size returned, to be overwritten instead of allocating six tensors again."""
         if not self.minibatches:
             raise RuntimeError("RolloutCollector.sample needs minibatches=True (or shaping=True): the next states are not recorded")
         if not self._filled:
@@ -244,6 +245,6 @@ class RolloutCollector:
         rewards = self.shaped if self.shaping else self.rewards
         out = ops.minibatch_gather(self.obs.reshape(T * n, 16), self.actions.view(T * n), self.logp.view(T * n),
                                    rewards.view(T * n), self.next_boards.view(T * n, 16), self.flags.view(T * n),
-                                   batch_size, seed, self._samples, want_indices=want_indices)
+                                   batch_size, seed, self._samples, want_indices=want_indices, out=out)
         self._samples += 1
         return out

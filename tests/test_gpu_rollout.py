@@ -338,6 +338,12 @@ def test_minibatch_sample_is_index_select_of_the_trajectory(g2048, oracle):
         assert whole["actions"].shape[0] == T * n
         a = rc.sample(32, generator=torch.Generator().manual_seed(5), want_indices=True)       # key taken from a CPU generator
         assert int(a["indices"].unique().numel()) == 32
+        first = a["indices"].clone()
+        b = rc.sample(32, out=a)                                                               # buffers reused: same dict, new draw
+        assert b is a and int(a["indices"].unique().numel()) == 32 and not torch.equal(a["indices"], first)
+        assert torch.equal(a["states"], flat(res["obs"]).index_select(0, a["indices"]))
+        with pytest.raises(ValueError):
+            rc.sample(33, out=a)
         if shaping:
             rc.check()
     with pytest.raises(RuntimeError, match="minibatches"):
