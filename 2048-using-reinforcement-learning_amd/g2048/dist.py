@@ -102,3 +102,13 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value, device):
+    """Every rank's `value` (one float per rank) in rank order, on every rank: the per-rank step times of the bench line."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]

@@ -102,6 +102,88 @@ class PreparedStep:
             L.check(rc)
 
 
+class StepChains:
+    """Launch form for independent sub-batches ("chains") of one batch of boards: contiguous slices of whole kernel blocks,
+    chain 0 on the caller's stream, chains 1..C-1 on side streams of their own. A chain's launches are ordered only behind
+    that chain's earlier launches, so one chain's launch head and drain overlap the others' arithmetic -- what a single
+    launch per step cannot do. Boards are independent and every draw is keyed by the global board id, so the
+    results are the single launch's bit for bit. This object only does the stream bookkeeping:
+
+        sc = StepChains(n, 2, device)
+        sc.fork()                                  # side streams wait for the current stream's work so far
+        for t in range(K):
+            for c, (lo, hi) in enumerate(sc.bounds):
+                with torch.cuda.stream(sc.stream(c)): ops.step(boards[lo:hi], ..., id_base + lo, ...)
+        sc.join()                                  # the current stream waits for every chain
+
+    Inside a hipGraph capture the same calls become one graph with C parallel branches. No host synchronisation anywhere."""
+
+    ALIGN = 256          # a chain owns whole blocks of the step kernel, and 16-byte aligned slices of every per-board array
+
+    def __init__(self, n, chains, device="cuda"):
+        n, chains = int(n), int(chains)
+        if chains < 1:
+            raise ValueError("g2048: chains must be at least 1")
+        self.device = torch.device(device)
+        per = -(-max(n, 1) // chains)
+        per = -(-per // self.ALIGN) * self.ALIGN
+        self.bounds = [(lo, min(lo + per, n)) for lo in range(0, max(n, 1), per)]       # fewer than `chains` slices for a small n
+        self._side = None
+        self._open_on = None        # the stream the open chains were forked from; None = joined
+        self._held = []             # inputs of open chains, kept alive until the join
+
+    def __len__(self):
+        return len(self.bounds)
+
+    @property
+    def is_open(self):
+        return self._open_on is not None
+
+    def keep_alive(self, *tensors):
+        """Side streams use these tensors: should they be freed with chains open, the allocator waits for the side streams."""
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in self.bounds[1:]]
+        for t in tensors:
+            for s in self._side:
+                t.record_stream(s)
+
+    def hold(self, tensor):
+        self._held.append(tensor)
+
+    def fork(self):
+        """Open the chains on the current stream (no-op if they are open on it already). Returns the current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._open_on is not None:
+            if self._open_on == cur:
+                return cur
+            self.join()             # the caller switched streams with chains open: close them where they were opened
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in self.bounds[1:]]
+        for s in self._side:
+            s.wait_stream(cur)
+        self._open_on = cur
+        return cur
+
+    def stream(self, c):
+        """The stream chain c launches on (valid between fork() and join())."""
+        return self._open_on if c == 0 else self._side[c - 1]
+
+    def fence(self):
+        """Open chains wait for everything queued on the current stream so far (inputs produced after the fork)."""
+        if self._open_on is not None:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self._side:
+                s.wait_stream(cur)
+
+    def join(self):
+        """The stream the chains were opened on waits for every chain's last launch. No-op when nothing is open."""
+        if self._open_on is not None:
+            for s in self._side:
+                self._open_on.wait_stream(s)
+            self._open_on = None
+            self._held.clear()
+
+
 def step_many(boards, scores, seed, step_index0, steps, id_base=0, out=None, flags=None, reward_stream=None,
               flags_stream=None, episodes=None, reward_f64=False, auto_reset=False, want_rewards=False, want_flags=False,
               want_episodes=False, actions=None):

@@ -170,3 +170,74 @@ def test_results_from_table_is_the_single_process_result():
     for k, m in enumerate(MILESTONES):
         assert r["milestones"][m] == [int(v) for v in t[:, 6 + k] if v >= 0]
     assert r["final_boards"].shape == (n, 4, 4) and r["summary"]["games"] == n
+
+
+def _eight_worker(rank, world, port, q, n_global, n_games):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from g2048 import dist as gdist
+    from g2048.evaluate import TABLE_COLUMNS
+    from oracle import oracle as O
+    O.set_num_threads(1)
+    w, r, _ = gdist.init("gloo", torch.device("cpu"))
+    assert (w, r) == (world, rank)
+    lo, hi = gdist.shard(n_global, rank, world)
+    b = O.synth_boards(hi - lo, seed=3, id_base=lo) if hi > lo else np.zeros((0, 16), np.uint8)
+    a = O.synth_actions(hi - lo, seed=3, step_index=2, id_base=lo) if hi > lo else np.zeros(0, np.uint8)
+    if hi > lo:
+        bo, sc, rw, fl = O.step_batch(b, a, np.zeros(hi - lo, np.uint32), seed=3, step_index=2, id_base=lo)
+    else:
+        sc, fl = np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+    gathered = gdist.all_gather_scores(torch.from_numpy(sc.astype(np.int32)))
+    m = torch.zeros(24, dtype=torch.int64)
+    m[0], m[1], m[2] = hi - lo, int(sc.sum()), int((fl & 1).sum())
+    gdist.reduce_metrics(m)
+    glo, ghi = gdist.shard(n_games, rank, world)
+    full = np.random.default_rng(5).integers(0, 1 << 40, size=(n_games, TABLE_COLUMNS), dtype=np.int64)
+    rows = gdist.all_gather_rows(torch.from_numpy(full[glo:ghi].copy()))
+    times = gdist.gather_floats(10.0 + rank, torch.device("cpu"))
+    slowest = gdist.max_over_ranks(10.0 + rank, torch.device("cpu"))
+    gdist.barrier()
+    q.put((rank, hi - lo, ghi - glo, gathered.numpy(), m.numpy(), rows.numpy(), times, slowest))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,n_games", [(20003, 37), (5, 3)])
+def test_eight_rank_gloo_ragged_and_empty_shards(oracle, n_global, n_games):
+    """The driver's rank count on CPU: world size 8 over gloo. dist.shard + all_gather_scores + reduce_metrics +
+    all_gather_rows + gather_floats + max_over_ranks with ragged shards (20,003 boards, 37 games) and with more ranks than units
+    (5 boards, 3 games: three / five ranks own nothing and still take part in every collective). EVERY rank must end up with the
+    single-process result in global id order."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q, n_global, n_games)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=240) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    b = oracle.synth_boards(n_global, seed=3)
+    a = oracle.synth_actions(n_global, seed=3, step_index=2)
+    bo, sc, rw, fl = oracle.step_batch(b, a, np.zeros(n_global, np.uint32), seed=3, step_index=2)
+    from g2048.evaluate import TABLE_COLUMNS
+    full = np.random.default_rng(5).integers(0, 1 << 40, size=(n_games, TABLE_COLUMNS), dtype=np.int64)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert sum(r[1] for r in res) == n_global and sum(r[2] for r in res) == n_games
+    if n_global < world:
+        assert sum(1 for r in res if r[1] == 0) == world - n_global
+    for rank, nb, ng, gathered, m, rows, times, slowest in res:
+        assert np.array_equal(gathered.astype(np.uint32), sc), rank
+        assert m[0] == n_global and m[1] == int(sc.sum()) and m[2] == int((fl & 1).sum())
+        assert np.array_equal(rows, full), rank
+        assert times == [10.0 + k for k in range(world)] and slowest == 17.0

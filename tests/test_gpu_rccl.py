@@ -131,3 +131,21 @@ def test_two_rank_sharded_evaluation_equals_one_process(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so[-2000:] + se[-4000:]
     assert "sharded ok" in outs[0][0]
+
+
+def test_a_failing_rank_takes_the_job_down():
+    """`python bench.py --gpus 2` with one rank raising right after the first barrier while the other goes on to wait at the
+    next one: the job must end non-zero within seconds (the failing rank leaves through os._exit, torchrun stops the other,
+    the launcher parent relays the code) -- not sit in the barrier until the driver's time limit. Two gloo ranks on one card."""
+    import time
+    env = dict(os.environ, G2048_DIST_BACKEND="gloo", G2048_BENCH_FAIL_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-beam",
+                          "--no-rollout", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert out.returncode != 0, "a rank failed but the job exited 0"
+    assert "injected failure on rank 1" in out.stderr
+    assert not any(l.startswith("{") for l in out.stdout.splitlines()), "no result line from a failed job"
+    assert took < 240, "the surviving rank waited %.0f s" % took

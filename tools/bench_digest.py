@@ -4,6 +4,16 @@ import sys
 r = json.load(open(sys.argv[1]))
 rf = r["roofline"]
 print("value %.3e ms/step %.4f frac %.3f kernel_us %.2f" % (r["value"], r["ms_per_step"], rf["frac"], rf["kernel_us"]))
+print("bound", rf.get("bound"), "| launch:", (r.get("config") or {}).get("launch", "")[:110])
+if "single_launch" in rf:
+    print("single launch: %.2f us frac %.3f plain %.2f us" % (rf["single_launch"]["kernel_us"], rf["single_launch"]["frac"], rf["single_launch"]["kernel_us_plain_launches"]))
+if "valu_issue" in rf:
+    v = rf["valu_issue"]
+    print("valu_issue: busy %.2f us/step by counter = %.3f of the step (single launch %.3f); model frac %.3f" % (
+        v["valu_busy_us_per_step_by_counter"], v["valu_busy_frac_by_counter"], v["valu_busy_frac_single_launch"], v["frac"]))
+if "rollout" in r and "roofline" in r["rollout"]:
+    x = r["rollout"]["roofline"]
+    print("rollout_step_kernel: %.2f us frac %.3f valu-busy %s" % (x["kernel_us"], x["frac"], x.get("valu_busy_frac_by_counter")))
 for k in ("roofline_f64_reward", "roofline_hbm_resident"):
     if k in r:
         print(k, "%.3f" % r[k]["frac"], "%.2f us" % r[k]["kernel_us"])
