@@ -15,6 +15,7 @@
 #include <atomic>
 
 #include "../../include/g2048.h"
+#include "../../include/g2048_testing.h"
 #include "g2048_board.h"
 #include "g2048_instrument.h"
 #include "g2048_rng.h"

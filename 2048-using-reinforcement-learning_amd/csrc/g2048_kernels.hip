@@ -12,6 +12,7 @@
 #include <stdio.h>
 
 #include "../../include/g2048.h"
+#include "../../include/g2048_testing.h"
 #include "g2048_board.h"
 #include "g2048_instrument.h"
 #include "g2048_rng.h"
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(kBlock) void replay_kernel(const uint4 *__restrict_
     const uint64_t id = in_range ? (game_ids ? (uint64_t)game_ids[k] : id_base + k) : 0ull;
     Board cur = in_range ? load_board(boards0, k) : Board{{0u, 0u, 0u, 0u}};
     uint32_t sc = (in_range && score0) ? score0[k] : 0u;
-    // (never beyond the history's room, whatever the caller's counts say)
-    const uint32_t len = in_range ? (uint32_t)min((size_t)max(n_moves[k], 0), hist_stride - 1u) : 0u;
+    // (never beyond the history's room nor beyond the game's row of action bytes, whatever the caller's counts say)
+    const uint32_t len = in_range ? (uint32_t)min(min((size_t)max(n_moves[k], 0), hist_stride - 1u), actions_stride) : 0u;
     const uint8_t *act = actions + k * actions_stride;
     uint4 *bh = boards_hist + k * hist_stride;
     uint32_t *sh = score_hist ? score_hist + k * hist_stride : nullptr;
@@ -752,6 +753,7 @@ int g2048_replay_games(const void *boards0, const uint32_t *score0_or_null, cons
         (score_hist_out_or_null && !aligned4(score_hist_out_or_null)) || (game_ids_or_null && (reinterpret_cast<uintptr_t>(game_ids_or_null) & 7u)))
         return fail(G2048_ERR_ARG, "g2048_replay_games: misaligned array");
     if (hist_stride == 0) return fail(G2048_ERR_ARG, "g2048_replay_games: hist_stride must be at least 1 (max moves + 1)");
+    if (actions_stride == 0) return fail(G2048_ERR_ARG, "g2048_replay_games: actions_stride must be at least 1 (bytes per game row)");
     hipLaunchKernelGGL(replay_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint4 *>(boards0), score0_or_null, reinterpret_cast<const unsigned long long *>(game_ids_or_null),
                        game_id_base, actions, actions_stride, n_moves, static_cast<uint4 *>(boards_hist_out), score_hist_out_or_null,

@@ -18,6 +18,7 @@
 #include <stdio.h>
 
 #include "../../include/g2048.h"
+#include "../../include/g2048_testing.h"
 #include "g2048_board.h"
 #include "g2048_rng.h"
 

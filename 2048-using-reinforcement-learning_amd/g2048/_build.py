@@ -13,9 +13,11 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB = os.environ.get("G2048_LIB") or os.path.join(CSRC, "libg2048_hip.so")     # G2048_LIB: A/B builds only (tools/)
 SOURCES = ["g2048_kernels.hip", "g2048_beam.hip", "g2048_rollout.hip"]
-PUBLIC_HEADER = os.path.join(CSRC, "..", "..", "include", "g2048.h")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+INCLUDE = os.path.join(CSRC, "..", "..", "include")
+PUBLIC_HEADERS = [os.path.join(INCLUDE, "g2048.h"), os.path.join(INCLUDE, "g2048_testing.h")]
+# -fvisibility=hidden: the export table is exactly what the two headers declare with G2048_API (tests/test_abi_and_host.py)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
+         "-Wl,--version-script=" + os.path.join(CSRC, "g2048_exports.map"), "-Wall", "-Wno-unused-function"]
 
 
 def needs_build():
@@ -23,7 +25,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     # every file a source can include is a dependency: whatever lies in csrc/ (sources, headers, .inc) + the public header
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".hpp"))] + [PUBLIC_HEADER]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".hpp", ".map"))] + PUBLIC_HEADERS
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -630,6 +630,14 @@ class _PerStream:
             return v
 
 
+class _ScratchBox:
+    """One (device, stream)'s scratch buffer and the lock that makes "grow if needed + enqueue" one step."""
+
+    def __init__(self):
+        import threading
+        self.buf, self.lock = None, threading.Lock()
+
+
 _BEAM_WS = _PerStream()
 _BEAM_HIST = _PerStream()
 
@@ -688,14 +696,20 @@ def beam_get_action(roots, width, depth, valid_mask=None, early_threshold=512, m
         key = (_dev_index(dev), tail[-1])
         if balanced_order == "sort":
             need = 0 if capturing else _size_query(dev, L.lib().g2048_beam_workspace_bytes, n)
-            ws = None
             if need:
-                box = _BEAM_WS.get(key, lambda: [None])
-                ws = box[0]
-                if ws is None or ws.numel() < need:
-                    ws = box[0] = torch.empty(need, dtype=torch.uint8, device=dev)
-            L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
-                   ws.data_ptr() if ws is not None else None, need, tail[-1])
+                # size check, allocation and enqueue under the entry's own lock: two host threads on one stream can neither
+                # replace each other's buffer before the launch nor launch into a buffer another thread just dropped (an entry
+                # evicted meanwhile keeps its buffer alive through `ws` until this launch is enqueued; the caching allocator's
+                # stream ordering covers the rest, the buffer having been allocated on this stream)
+                box = _BEAM_WS.get(key, _ScratchBox)
+                with box.lock:
+                    ws = box.buf
+                    if ws is None or ws.numel() < need:
+                        ws = box.buf = torch.empty(need, dtype=torch.uint8, device=dev)
+                    L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1],
+                           ws.data_ptr(), need, tail[-1])
+            else:
+                L.call(dev, L.lib().g2048_beam_get_action_ws, *head, L.u64(seed), L.u64(step_index), *tail[:-1], None, 0, tail[-1])
         else:
             need = 0 if (not balanced_order or capturing) else _size_query(dev, L.lib().g2048_beam_history_bytes, n)
             if not need:

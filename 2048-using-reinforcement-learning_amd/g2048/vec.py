@@ -43,7 +43,7 @@ class VecGame2048:
     its own on its own stream, ordered only behind the same slice's previous step. Boards are independent, so the result
     is the single launch's bit for bit (draws are keyed by global board id); what changes is the launch form: one
     chain's launch head and drain overlap the other chains' arithmetic, which a single launch per step cannot do
-    (13.3 -> 9.8-11.2 us per 1 Mi-board step with two chains inside a hipGraph). `step(..., join=False)`
+    (13.2-13.9 -> 10.4-11.9 us per 1 Mi-board step with two chains on two streams). `step(..., join=False)`
     leaves the chains open across steps -- that is where the overlap comes from; see `step` and `join`.
     """
 

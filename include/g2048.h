@@ -37,11 +37,17 @@
 #define G2048_H
 #include <stddef.h>
 #include <stdint.h>
+/* Every entry point below is exported (the library is built with -fvisibility=hidden: nothing else is). */
+#ifndef G2048_API
+#define G2048_API __attribute__((visibility("default")))
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 3        /* 3: round 4 (actions_out of the g2048_play_games family, g2048_replay_games, g2048_env_step,
+#define G2048_ABI_VERSION 4        /* 4: round 5 (export table = this header + g2048_testing.h exactly: test / measurement hooks moved there,
+                                      internal symbols hidden; g2048_replay_games also clamps a game's length to actions_stride)
+                                      3: round 4 (actions_out of the g2048_play_games family, g2048_replay_games, g2048_env_step,
                                       g2048_minibatch_gather, g2048_build_flags; the A/B variants of g2048_step / g2048_sort_selftest gone)
                                       2: round 3 (g2048_step_many, g2048_play_games_tuned, g2048_launch_plan, g2048_device_plan,
                                       g2048_beam_get_action_hist; no env hook) */
@@ -102,18 +108,18 @@ enum {
 
 #define G2048_BEAM_MAX_WIDTH   128
 
-const char *g2048_last_error(void);
-int g2048_abi_version(void);
+G2048_API const char *g2048_last_error(void);
+G2048_API int g2048_abi_version(void);
 /* 0 for the product library. Non-zero: a measurement build (csrc/g2048_instrument.h: bit 0 beam timeline, bit 1 evaluation
  * timeline, bit 2 step timeline) that overwrites real outputs with clock ticks -- never use its results. */
-unsigned g2048_build_flags(void);
+G2048_API unsigned g2048_build_flags(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
-int g2048_device_count(void);
+G2048_API int g2048_device_count(void);
 
 /* Game2048Env.step for n boards (environment/game_2048.py:170-210): move, validity, spawn iff valid,
  * shaped reward (:212-277), done (:279-288). boards_out may alias boards_in. Draw for board i:
  * (seed, STEP, step_index, board_id_base + i). */
-int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out,
+G2048_API int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out,
                uint32_t *score_inout, void *reward_out, uint8_t *flags_out,
                uint64_t seed, uint64_t step_index, uint64_t board_id_base, size_t n,
                uint32_t opts, void *stream);
@@ -129,34 +135,34 @@ int g2048_step(const void *boards_in, const uint8_t *actions, void *boards_out,
  * Outputs: the boards and scores after the last step, flags_last_out[i] = the flags byte of the last step; optional per-step
  * streams, step-major: reward_stream_out_or_null[t * n + i] (float, or double with G2048_STEP_REWARD_F64) and
  * flags_stream_out_or_null[t * n + i]; episodes_out_or_null[i] = episodes board i finished (auto-resets taken). */
-int g2048_step_many(const void *boards_in, const uint8_t *actions_stream_or_null, void *boards_out, uint32_t *score_inout,
+G2048_API int g2048_step_many(const void *boards_in, const uint8_t *actions_stream_or_null, void *boards_out, uint32_t *score_inout,
                     void *reward_stream_out_or_null, uint8_t *flags_stream_out_or_null, uint8_t *flags_last_out,
                     uint32_t *episodes_out_or_null, uint64_t seed, uint64_t step_index0, uint32_t steps,
                     uint64_t board_id_base, size_t n, uint32_t opts, void *stream);
 
 /* Game2048Env.reset for n boards (environment/game_2048.py:29-48). score_out may be NULL. */
-int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch,
+G2048_API int g2048_reset(void *boards_out, uint32_t *score_out, uint64_t seed, uint64_t epoch,
                 uint64_t board_id_base, size_t n, void *stream);
 
 /* get_valid_moves / _check_valid_moves: mask4_out[i] bit a = action a valid (0 LEFT 1 UP 2 RIGHT 3 DOWN). */
-int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t opts, void *stream);
+G2048_API int g2048_valid_moves(const void *boards, uint8_t *mask4_out, size_t n, uint32_t opts, void *stream);
 
 /* board heuristics, f64 out. phase_or_null: per-board 0 early / 1 mid / 2 late for G2048_EVAL_FULL
  * (NULL = derive from the board's own max tile with thresholds 512 / 1024, beam_search_agent.py:271-278). */
-int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream);
+G2048_API int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, double *out, size_t n, void *stream);
 
 /* PPOAgent.normalize_state (agents/ppo_agent.py:184-195): obs_out[i*16+j] = float32(code)/float32(15). */
-int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream);
+G2048_API int g2048_obs_f32(const void *boards, float *obs_out, size_t n, void *stream);
 
 /* the same observation in 16 bits: obs_out is n*16 IEEE half (bf16 = 0) or bfloat16 (bf16 = 1) values, each the f32
  * quotient above rounded to nearest even -- for policies that run in reduced precision (32 B per board instead of 64) */
-int g2048_obs_16(const void *boards, void *obs_out, int bf16, size_t n, void *stream);
+G2048_API int g2048_obs_16(const void *boards, void *obs_out, int bf16, size_t n, void *stream);
 
 /* BeamSearchAgent.get_action for n_games roots (agents/beam_search_agent.py:71-181).
  * valid_mask_or_null: caller-supplied masks (the `valid_moves` argument), NULL = None.
  * expanded_out_or_null: children generated per game (calls of _add_random_tile).
  * Draw j of game g: (seed, BEAM, step_index, game_id_base + g, j) in the reference's generation order. */
-int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null,
+G2048_API int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_null,
                           uint8_t *action_out, float *prob_out, uint32_t *expanded_out_or_null,
                           int width, int depth, int early_threshold, int mid_threshold,
                           uint64_t seed, uint64_t step_index, uint64_t game_id_base, size_t n_games,
@@ -164,8 +170,8 @@ int g2048_beam_get_action(const void *root_boards, const uint8_t *valid_mask_or_
 /* The same with g2048_beam_workspace_bytes(n_games) bytes of caller-provided device scratch: from 4096 games per
  * call on, the blocks then take the games in a depth-balanced order (deep and shallow searches mixed on every SIMD) -- same
  * results, a shorter launch. workspace NULL, or a batch for which the query returns 0: exactly g2048_beam_get_action. */
-size_t g2048_beam_workspace_bytes(size_t n_games);
-int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+G2048_API size_t g2048_beam_workspace_bytes(size_t n_games);
+G2048_API int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
                              float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                              int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
                              uint64_t game_id_base, size_t n_games, uint32_t opts, void *workspace,
@@ -178,8 +184,8 @@ int g2048_beam_get_action_ws(const void *root_boards, const uint8_t *valid_mask_
  * it) of the last call that used it; call_index counts 1, 2, 3, ... . A call that finds no usable history takes the games in
  * caller order. history NULL, or a batch for which the query returns 0: exactly g2048_beam_get_action. One buffer serves one
  * stream of calls; it must not be shared by calls that may run concurrently. */
-size_t g2048_beam_history_bytes(size_t n_games);
-int g2048_beam_get_action_hist(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+G2048_API size_t g2048_beam_history_bytes(size_t n_games);
+G2048_API int g2048_beam_get_action_hist(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
                                float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                                int early_threshold, int mid_threshold, uint64_t seed, uint64_t step_index,
                                uint64_t game_id_base, size_t n_games, uint32_t opts, void *history, size_t history_bytes,
@@ -190,7 +196,7 @@ int g2048_beam_get_action_hist(const void *root_boards, const uint8_t *valid_mas
  * -1 = not reached yet) records move_index the first time the max tile reaches it, the valid / invalid / total move
  * counters advance, expanded_or_null[i] is added to expanded_sum, and the game leaves `alive` when its DONE flag is
  * set. Games not alive are untouched. */
-int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
+G2048_API int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout, int32_t *moves_inout,
                          int32_t *valid_inout, int32_t *invalid_inout, int32_t *milestone_move_inout,
                          unsigned long long *expanded_sum_inout_or_null, int32_t move_index, size_t n, void *stream);
 
@@ -199,7 +205,7 @@ int g2048_track_episodes(const uint8_t *flags, const uint32_t *expanded_or_null,
  * weights p_a + 1e-10 over the valid actions (what Categorical(logits = log(p + 1e-10) + mask) samples) by inverse
  * CDF with draw (seed, POLICY, step_index, env_id_base + i); prob_out[i] = its probability (take the log for
  * the reference's `action_prob`). */
-int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+G2048_API int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
                          uint64_t seed, uint64_t step_index, uint64_t env_id_base, size_t n, void *stream);
 
 /* Game2048Env.simulate_move (environment/game_2048.py:341-387) for n (state, action) pairs: every successor the
@@ -208,7 +214,7 @@ int g2048_sample_actions(const float *probs, const uint8_t *mask4_or_null, uint8
  * includes the milestone bonus against highest_code, the env's highest_tile attribute as a log2 code; NULL = the
  * state's own max, as inside an episode). Outputs are 32 slots per state: succ_boards_out n*32 boards,
  * reward_out n*32 f64, done_out n*32 bytes; count_out[i] = number of valid slots (0 when the move is invalid). */
-int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null,
+G2048_API int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_t *highest_code_or_null,
                         void *succ_boards_out, double *reward_out, uint8_t *done_out, uint8_t *count_out,
                         size_t n, void *stream);
 
@@ -219,7 +225,7 @@ int g2048_simulate_move(const void *boards, const uint8_t *actions, const uint8_
  * bytes; count_out[i] = valid slots: 1 for a move that changes nothing (the board itself, reward -1.0), else 2 * min(3,
  * empty cells), successor 2j / 2j+1 = pick j with a 2 / a 4. Pick j of state i is the idx(h_j, n_empty - j)-th empty
  * cell (row-major) not picked before, h_j = draw (seed, SIMULATE, step_index, state_id_base + i, j). */
-int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void *succ_boards_out, double *reward_out,
+G2048_API int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void *succ_boards_out, double *reward_out,
                                 uint8_t *done_out, uint8_t *count_out, uint64_t seed, uint64_t step_index,
                                 uint64_t state_id_base, size_t n, void *stream);
 
@@ -239,13 +245,13 @@ int g2048_simulate_move_sampled(const void *boards, const uint8_t *actions, void
  * 0xFF from the game's end on (the library fills the array with 0xFF before the launch). One byte per move is also all that is
  * needed to rebuild the per-move histories of evaluate_beam_search.py:44-50, :72-75 afterwards: g2048_replay_games. The bytes do
  * not depend on helper wavefronts, tuning or the ranking switch. */
-int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
+G2048_API int g2048_play_games(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                      int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
                      uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
                      int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
                      void *stream);
-size_t g2048_play_games_workspace(size_t n_games);
-int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
+G2048_API size_t g2048_play_games_workspace(size_t n_games);
+G2048_API int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
                         int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
                         uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
                         int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
@@ -258,36 +264,13 @@ int g2048_play_games_ws(void *boards_inout, uint32_t *score_inout, int32_t *move
  * when it wrote those bytes; an action byte above 3 (0xFF = no move) ends that game's replay early. Outputs, hist_stride
  * entries per game (hist_stride > the longest game): boards_hist_out[k * hist_stride + t] = the board BEFORE move t (t = 0 the
  * start, t = n_moves[k] the final board), score_hist_out likewise, flags_hist_out[k * hist_stride + t] = the flags byte of move
- * t (DONE / VALID / max code after the move: bits 3..7 give max_tiles_history). Entries past a game's end are left untouched. */
-int g2048_replay_games(const void *boards0, const uint32_t *score0_or_null, const uint64_t *game_ids_or_null, uint64_t game_id_base,
+ * t (DONE / VALID / max code after the move: bits 3..7 give max_tiles_history). Entries past a game's end are left untouched.
+ * A game's length is clamped to min(n_moves[k], hist_stride - 1, actions_stride): the kernel never reads past a game's row of
+ * action bytes nor writes past its row of the history; actions_stride = 0 or hist_stride = 0 is refused. */
+G2048_API int g2048_replay_games(const void *boards0, const uint32_t *score0_or_null, const uint64_t *game_ids_or_null, uint64_t game_id_base,
                        const uint8_t *actions, size_t actions_stride, const int32_t *n_moves, void *boards_hist_out,
                        uint32_t *score_hist_out_or_null, uint8_t *flags_hist_out_or_null, size_t hist_stride, uint64_t seed,
                        size_t n, void *stream);
-
-/* g2048_play_games_ws with the helper-wavefront parameters given explicitly -- a measurement / test interface (the games are
- * the same for every setting; only the time changes). tuning4 = { helper wavefronts (clamped to 8 per game and to the
- * device's cap, g2048_launch_plan), games left at which every remaining game registers for helpers (>= n_games: at once),
- * "stuck" threshold = invalid minus valid moves at which a game registers early (clamped to 1 .. 2^20), microseconds an
- * owner polls for a posted result (clamped to 1000) }. The defaults g2048_play_games uses: { min(8 n, max(n / 2, 1024), cap),
- * max(n / 8, 256), 16, 150 }. */
-int g2048_play_games_tuned(void *boards_inout, uint32_t *score_inout, int32_t *moves_out, int32_t *valid_out,
-                           int32_t *invalid_out, int32_t *milestone_move_out, unsigned long long *expanded_sum_out_or_null,
-                           uint8_t *alive_out, uint8_t *actions_out_or_null, int width, int depth, int early_threshold,
-                           int mid_threshold, int max_moves, uint64_t seed, uint64_t game_id_base, size_t n_games, uint32_t opts,
-                           void *workspace, size_t workspace_bytes, const uint32_t *tuning4, void *stream);
-
-/* The launch arithmetic the library derives from the device's size, as a pure host function (no launch, no allocation):
- * out4 = { SIMD row length beam batches are dealt in (4 per compute unit), smallest batch that gets the depth-balanced
- * order (four searches per SIMD), most helper wavefronts a g2048_play_games launch may carry (a quarter of the wavefronts
- * the device holds at once: compute_units x resident_blocks_per_cu / 4), default helper wavefronts for n_games }.
- * compute_units = 0: the current device's count; resident_blocks_per_cu = 0: 32 (the hardware cap for 64-thread blocks). */
-int g2048_launch_plan(int compute_units, int resident_blocks_per_cu, size_t n_games, uint32_t *out4);
-
-/* What the library asks the CURRENT device before a beam / evaluation launch of this width and size (host only):
- * out6 = { compute units, blocks of the evaluation kernel one compute unit holds (occupancy query), helper-wavefront cap,
- * default helper wavefronts for n_games, blocks of the beam kernel the device holds at once, 1 if a g2048_beam_get_action
- * launch of n_games runs with issue priority by remaining levels (every block resident at once), else 0 }. */
-int g2048_device_plan(int width, size_t n_games, uint32_t *out6);
 
 /* ONE env driven from a host loop -- the drop-in Game2048Env of train.py:55-75 -- in one launch per iteration: op STEP =
  * Game2048Env.step(action) (environment/game_2048.py:170-210; an action outside 0..3 moves nothing, :97-114; draw (seed, STEP,
@@ -301,25 +284,17 @@ int g2048_device_plan(int width, size_t n_games, uint32_t *out6);
 #define G2048_ENV_OP_STEP  0u
 #define G2048_ENV_OP_RESET 1u
 #define G2048_ENV_OP_PEEK  2u
-int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
+G2048_API int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
                    uint64_t index, uint64_t board_id, void *stream);
 
 /* reference state layout (np.int32[16] real tile values, game_2048.py:36,57) <-> packed codes */
-int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
-int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream);
-
-/* synthetic inputs of the benchmark configs, generated on the device:
- * each cell empty with probability p_empty_u16/65536 else code uniform in 1..max_code; an all-empty
- * draw gets code 1 at cell 0. actions: uniform 0..3. */
-int g2048_synth_boards(void *boards_out, uint64_t seed, uint64_t board_id_base, size_t n,
-                       uint32_t p_empty_u16, uint32_t max_code, void *stream);
-int g2048_synth_actions(uint8_t *actions_out, uint64_t seed, uint64_t step_index,
-                        uint64_t board_id_base, size_t n, void *stream);
+G2048_API int g2048_pack_i32(const int32_t *tiles, void *boards_out, size_t n, void *stream);
+G2048_API int g2048_unpack_i32(const void *boards, int32_t *tiles_out, size_t n, void *stream);
 
 /* per-shard metrics for the multi-GPU reduction: out[0] = n, out[1] = sum(score), out[2] = #done,
  * out[3] = sum(expanded or 0), out[4..22) = histogram of max code 0..17. out must hold 24 uint64,
  * and is accumulated into (zero it first). flags/expanded may be NULL. */
-int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flags_or_null,
+G2048_API int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flags_or_null,
                   const uint32_t *expanded_or_null, unsigned long long *out24, size_t n, void *stream);
 
 /* ---- graph-replayable loops -------------------------------------------------------------------------------
@@ -330,17 +305,17 @@ int g2048_metrics(const void *boards, const uint32_t *score, const uint8_t *flag
  * g2048_track_episodes_dyn its move index) from that block. Results are identical to the scalar forms called with
  * step_index = the counter's value. */
 #define G2048_KEYBLOCK_WORDS 16
-int g2048_keys_advance(uint32_t *keyblock_out, unsigned long long *counter_inout, uint64_t seed, void *stream);
-int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
+G2048_API int g2048_keys_advance(uint32_t *keyblock_out, unsigned long long *counter_inout, uint64_t seed, void *stream);
+G2048_API int g2048_step_dyn(const void *boards_in, const uint8_t *actions, void *boards_out, uint32_t *score_inout,
                    void *reward_out, uint8_t *flags_out, const uint32_t *keyblock, uint64_t board_id_base, size_t n,
                    uint32_t opts, void *stream);
-int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
+G2048_API int g2048_beam_get_action_dyn(const void *root_boards, const uint8_t *valid_mask_or_null, uint8_t *action_out,
                               float *prob_out, uint32_t *expanded_out_or_null, int width, int depth,
                               int early_threshold, int mid_threshold, const uint32_t *keyblock,
                               uint64_t game_id_base, size_t n_games, uint32_t opts, void *stream);
-int g2048_sample_actions_dyn(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
+G2048_API int g2048_sample_actions_dyn(const float *probs, const uint8_t *mask4_or_null, uint8_t *actions_out, float *prob_out,
                              const uint32_t *keyblock, uint64_t env_id_base, size_t n, void *stream);
-int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout,
+G2048_API int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_null, uint8_t *alive_inout,
                              int32_t *moves_inout, int32_t *valid_inout, int32_t *invalid_inout,
                              int32_t *milestone_move_inout, unsigned long long *expanded_sum_inout_or_null,
                              const uint32_t *keyblock, size_t n, void *stream);
@@ -361,7 +336,7 @@ int g2048_track_episodes_dyn(const uint8_t *flags, const uint32_t *expanded_or_n
 #define G2048_OBS_F32  0u
 #define G2048_OBS_F16  1u
 #define G2048_OBS_BF16 2u
-int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t *mask4_in_or_null, void *boards_out,
+G2048_API int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t *mask4_in_or_null, void *boards_out,
                        uint32_t *score_inout, uint8_t *actions_out, float *prob_out, void *reward_out, uint8_t *flags_out,
                        void *obs_next_out_or_null, uint8_t *mask4_next_out_or_null, void *next_boards_out_or_null,
                        uint8_t *state_maxcode_out_or_null, uint64_t seed, uint64_t step_index,
@@ -377,7 +352,7 @@ int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t 
  * (the next states BEFORE any auto-reset, as g2048_rollout_step writes them) and flags. Outputs, what update() turns the sample
  * into: states_out float32 [batch][16], actions_out int64, old_log_probs_out float32, rewards_out float32, next_states_out
  * float32 [batch][16] = normalize_state(next state) (:184-195), dones_out float32 (1.0 = done), and optionally the indices. */
-int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *actions, const float *log_probs, const void *rewards,
+G2048_API int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *actions, const float *log_probs, const void *rewards,
                            uint32_t rewards_f64, const void *next_boards, const uint8_t *flags, size_t n_transitions, size_t batch,
                            uint64_t seed, uint64_t sample_index, float *states_out, int64_t *actions_out, float *old_log_probs_out,
                            float *rewards_out, float *next_states_out, float *dones_out, int64_t *indices_out_or_null, void *stream);
@@ -406,24 +381,16 @@ int g2048_minibatch_gather(const void *obs, uint32_t obs_kind, const uint8_t *ac
  * The only deviation from the reference: its set holds Python hash() values of the board bytes, so two different boards
  * whose 64-bit hashes collide count as one there; here keys are compared in full. */
 #define G2048_SEEN_SLOT_BYTES 32
-size_t g2048_shaping_scan_workspace(size_t n);
-int g2048_shaping_scan(const uint8_t *flags, uint8_t *prev_highest_out, uint32_t *highest_code_inout, void *workspace,
+G2048_API size_t g2048_shaping_scan_workspace(size_t n);
+G2048_API int g2048_shaping_scan(const uint8_t *flags, uint8_t *prev_highest_out, uint32_t *highest_code_inout, void *workspace,
                        size_t n, void *stream);
-int g2048_seen_insert(const void *next_boards, uint64_t index_base, void *table, uint32_t capacity_log2,
+G2048_API int g2048_seen_insert(const void *next_boards, uint64_t index_base, void *table, uint32_t capacity_log2,
                       unsigned long long *count_inout, uint32_t *overflow_flag, uint32_t *slot_out, size_t n, void *stream);
-int g2048_seen_rehash(const void *old_table, uint32_t old_capacity_log2, void *new_table, uint32_t new_capacity_log2,
+G2048_API int g2048_seen_rehash(const void *old_table, uint32_t old_capacity_log2, void *new_table, uint32_t new_capacity_log2,
                       uint32_t *overflow_flag, void *stream);
-int g2048_shaping_apply(const void *next_boards, const uint8_t *state_maxcode, const uint8_t *flags, const double *env_reward,
+G2048_API int g2048_shaping_apply(const void *next_boards, const uint8_t *state_maxcode, const uint8_t *flags, const double *env_reward,
                         const uint8_t *prev_highest, const void *table, const uint32_t *slots, uint64_t index_base,
                         double *shaped_out, uint8_t *novel_out_or_null, size_t n, void *stream);
-
-/* device self-test of the instruction-level assumptions the kernels rely on (v_perm_b32 byte order,
- * udot4, f64 contraction off). Writes 0 to *result_out (device uint32) when all hold. */
-int g2048_selftest(uint32_t *result_out, void *stream);
-/* the beam kernel's ranking network on its own (tests): every 64 keys of keys_inout become the 64 largest, descending, of
- * those 64 and -- if extra_or_null is given -- 16 more per block (0 = no key; all other keys distinct and > 0).
- * key_bits = 32: uint32 keys; 64: uint64 keys stored as (low word, high word), the network of the f64-score levels. */
-int g2048_sort_selftest(uint32_t *keys_inout, const uint32_t *extra_or_null, size_t n_waves, int key_bits, void *stream);
 
 #ifdef __cplusplus
 }

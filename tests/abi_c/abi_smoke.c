@@ -25,6 +25,7 @@ const char *hipGetErrorString(hipError_t e);
 #include <stdlib.h>
 
 #include "g2048.h"
+#include "g2048_testing.h"   /* synthetic benchmark inputs (g2048_synth_*) */
 
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 #define CHECK_G(x) do { int r_ = (x); if (r_ != G2048_OK) { fprintf(stderr, "g2048 error %d: %s\n", r_, g2048_last_error()); return 3; } } while (0)

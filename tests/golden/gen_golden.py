@@ -659,11 +659,13 @@ def gen_games():
     STEP, t, game id, 0). Recorded per game: what run_game returns beyond the counters -- board_history, scores_history,
     max_tiles_history, milestones -- and train.py's moveset. Small beams keep the reference's Python search affordable (three games at
     width 3 / depth 4 and four greedy ones run to their end or the 5000-move cap, three at width 4 / depth 5 are cut at 250 moves); two
-    games at the evaluation configuration (width 20, depth 30) are cut at 30 moves."""
+    games at the evaluation configuration (width 20, depth 30) are cut at 30 moves, and (round 5) three more at that configuration are
+    played to their END under the evaluation's 5000-move cap (run_evaluation.py:48-69; ~0.13 s per decision in the reference's Python,
+    2-4 minutes per game) -- the reference's own headline configuration pinned end to end."""
     env = Game2048Env()
     out, meta = {}, []
     t0 = time.time()
-    configs = [(3, 4, 5000, 3), (1, 1, 5000, 4), (4, 5, 250, 3), (20, 30, 30, 2)]          # width, depth, move cap, games
+    configs = [(3, 4, 5000, 3), (1, 1, 5000, 4), (4, 5, 250, 3), (20, 30, 30, 2), (20, 30, 5000, 3)]      # width, depth, move cap, games
     gid = 7000
     k = 0
     for w, d, cap, ngames in configs:

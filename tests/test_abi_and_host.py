@@ -21,22 +21,41 @@ def built():
     return _lib
 
 
-def declared_symbols():
-    hdr = open(os.path.join(REPO, "include", "g2048.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(g2048_[a-z0-9_]+)\s*\(", hdr)))
+PUBLIC_HEADERS = ("g2048.h", "g2048_testing.h")
+TESTING_HOOKS = {"g2048_selftest", "g2048_sort_selftest", "g2048_play_games_tuned", "g2048_launch_plan", "g2048_device_plan",
+                 "g2048_synth_boards", "g2048_synth_actions"}
 
 
-def test_header_symbols_exported(built):
+def declared_symbols(header=None):
+    names = set()
+    for h in ([header] if header else PUBLIC_HEADERS):
+        hdr = open(os.path.join(REPO, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        found = set(re.findall(r"\b(g2048_[a-z0-9_]+)\s*\(", hdr))
+        exported = set(re.findall(r"\bG2048_API\s+[^;(]*?\b(g2048_[a-z0-9_]+)\s*\(", hdr))
+        assert found == exported, "%s: declarations without G2048_API: %s" % (h, sorted(found - exported))
+        names |= found
+    return sorted(names)
+
+
+def test_export_table_equals_the_two_headers(built):
+    """The library's dynamic symbol table is EXACTLY what include/g2048.h (the drop-in boundary) and include/g2048_testing.h
+    (test / measurement / benchmark-input hooks) declare: -fvisibility=hidden + G2048_API + csrc/g2048_exports.map. No internal
+    helper, no mangled C++ symbol, no toolchain marker leaks; nothing declared is missing."""
+    import subprocess
     names = declared_symbols()
     assert len(names) >= 15 and "g2048_step" in names and "g2048_beam_get_action" in names
-    L = C.CDLL(built.library_path())
-    for n in names:
-        assert hasattr(L, n), "symbol %s declared in include/g2048.h is not exported" % n
-    assert set(names) == set(built.SIGNATURES), "python binding table and header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built.library_path()], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == names, "only in the library: %s; only in the headers: %s" % (sorted(set(exported) - set(names)),
+                                                                                     sorted(set(names) - set(exported)))
+    assert set(names) == set(built.SIGNATURES), "python binding table and headers disagree"
+    # what a maintainer binds is the boundary header; the hooks live apart
+    assert set(declared_symbols("g2048_testing.h")) == TESTING_HOOKS
+    assert not TESTING_HOOKS & set(declared_symbols("g2048.h"))
     hdr = open(os.path.join(REPO, "include", "g2048.h")).read()
     version = int(re.search(r"#define G2048_ABI_VERSION (\d+)", hdr).group(1))
-    assert version == 3 and built.lib().g2048_abi_version() == version == built.ABI_VERSION       # bumped whenever the entry points change
+    assert version == 4 and built.lib().g2048_abi_version() == version == built.ABI_VERSION       # bumped whenever the entry points change
     assert built.lib().g2048_device_count() >= 0
 
 

@@ -426,3 +426,29 @@ def test_complete_games_of_the_real_reference(g2048):
             assert game["milestones"] == want_ms, j
             assert not done or res["final_boards"][i].min() > 0                   # a finished game ends on a full board
         k = group[-1] + 1
+
+
+@pytest.mark.timeout(400, method="thread")
+@pytest.mark.parametrize("n,w,d,cap", [(9000, 4, 3, 60), (20000, 3, 3, 50), (65536, 2, 2, 40), (65537, 2, 2, 40)])
+def test_helpers_between_4096_games_and_the_cut_off(g2048, n, w, d, cap):
+    """The fused evaluation (run_evaluation.py:48-69 per game) at the batch sizes nothing else runs: launches far larger than
+    the chip holds at once (owners that start late, helper blocks dispatched last) up to 65,536 games, the last size with
+    helper wavefronts, and 65,537, the first without (g2048_play_games_workspace = 0 there). Tiny searches and a short move
+    cap keep it to seconds. With helpers == G2048_PLAY_ONE_PHASE: final boards, scores, every counter, milestone and action
+    byte."""
+    from g2048 import ops, _lib as L
+    dev = torch.device("cuda")
+    ws_bytes = int(L.lib().g2048_play_games_workspace(n))
+    assert (ws_bytes > 0) == (n <= 65536)
+    runs = []
+    for one_phase in (True, False):
+        b, s = ops.reset(n, 515, 0, 3 << 34, device=dev)
+        r = ops.play_games(b, s, w, d, max_moves=cap, seed=515, game_id_base=3 << 34, one_phase=one_phase, want_actions=True)
+        torch.cuda.synchronize()
+        runs.append((b, s, r))
+    (b0, s0, r0), (b1, s1, r1) = runs
+    assert torch.equal(b0, b1) and torch.equal(s0, s1)
+    for k in ("moves", "valid_moves", "invalid_moves", "milestone_move", "expanded", "alive", "actions"):
+        assert torch.equal(r0[k], r1[k]), k
+    moves = r0["moves"]
+    assert int(moves.max()) == cap and int(moves.min()) >= 1 and int(r0["expanded"].sum()) > n        # games were really played

@@ -12,7 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.import_package()
-from g2048 import ops
+from g2048 import ops, _lib
+if len(sys.argv) > 1 and sys.argv[1] == "timeline":
+    assert _lib.lib().g2048_build_flags() & 1, "the timeline pass needs a -DG2048_INSTRUMENT=1 build (tools/build_ab.sh timing -DG2048_INSTRUMENT=1; G2048_LIB=build_ab/libg2048_timing.so): a product build's outputs are results, not clock ticks"
 import bench
 bench.torch = torch
 SEED = 0x2048

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.import_package()
-from g2048 import ops
+from g2048 import ops, _lib
+assert _lib.lib().g2048_build_flags() & 2, "needs a -DG2048_INSTRUMENT=2 build (tools/build_ab.sh NAME -DG2048_INSTRUMENT=2; G2048_LIB=build_ab/libg2048_NAME.so): a product build's outputs are results, not clock ticks"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda")
 for rep in range(2):
