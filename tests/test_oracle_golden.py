@@ -252,13 +252,17 @@ MILESTONES = (64, 128, 256, 512, 1024, 2048, 4096, 8192)
 
 
 def test_complete_games_golden(oracle):
-    """tests/golden/games.npz: twelve games played by the REAL Game2048Env + BeamSearchAgent in the shape of the reference's
+    """tests/golden/games.npz: fifteen games played by the REAL Game2048Env + BeamSearchAgent in the shape of the reference's
     run_game (evaluate_beam_search.py:29-98): complete ones (done, and one stuck at the 5000-move cap), cut ones, two at the
-    evaluation configuration. The oracle playing the same games decides every move the same way and passes through the same
+    evaluation configuration cut at 30 moves and -- round 5 -- three COMPLETE games at that configuration (width 20, depth 30,
+    5000-move cap: 532, 915 and 1539 moves, the last one reaching 2048), the reference's own headline setting end to end
+    (run_evaluation.py:48-69). The oracle playing the same games decides every move the same way and passes through the same
     boards, scores, max tiles and milestones -- the pin behind the move-sets / histories the GPU path records and replays."""
     g = load_golden("games.npz")
     seed = int(g["seed"])
-    assert g["meta"].shape[0] == 12 and int(g["meta"][:, 8].sum()) >= 6 and int((g["meta"][:, 4] == 5000).sum()) == 1
+    assert g["meta"].shape[0] == 15 and int(g["meta"][:, 8].sum()) >= 9 and int((g["meta"][:, 4] == 5000).sum()) == 1
+    full = [m for m in g["meta"].tolist() if (m[0], m[1], m[2]) == (20, 30, 5000)]
+    assert len(full) == 3 and all(m[8] == 1 for m in full) and max(m[4] for m in full) > 1500         # complete (20, 30) games
     for k, (w, d, cap, gid, moves, valid_n, invalid_n, score, done) in enumerate(g["meta"].tolist()):
         if moves > 1500:                  # (the capped game: its first 1500 moves are enough for the CPU suite; the GPU test plays all 5000)
             moves = 1500
