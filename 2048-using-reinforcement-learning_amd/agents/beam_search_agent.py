@@ -52,6 +52,25 @@ class BeamSearchAgent:
         self._calls += 1
         return int(actions.item()), float(probs.item())
 
+    # -- the reference's per-board helpers, for scripts that call them directly (one board, one small launch each) ----------
+    def _codes(self, board):
+        tiles = torch.as_tensor(np.ascontiguousarray(board, dtype=np.int32).reshape(1, 16), device=self.device)
+        return ops.pack(tiles)
+
+    def _determine_game_phase(self, max_tile):                                          # reference :271-278
+        return "early" if max_tile < self.early_game_threshold else "mid" if max_tile < self.mid_game_threshold else "late"
+
+    def _check_valid_moves(self, board):                                                # reference :183-192 (DOWN quirk included)
+        m = int(ops.valid_moves(self._codes(board), agent_semantics=True).item())
+        return [bool((m >> a) & 1) for a in range(4)]
+
+    def _fast_evaluate(self, board, game_phase=None):                                   # reference :280-314 (the phase is ignored there too)
+        return float(ops.evaluate(self._codes(board), L.EVAL_FAST).item())
+
+    def _evaluate_state(self, board, game_phase):                                       # reference :316-373
+        phase = torch.tensor([("early", "mid", "late").index(game_phase)], dtype=torch.uint8, device=self.device)
+        return float(ops.evaluate(self._codes(board), L.EVAL_FULL, phase).item())
+
     def remember(self, *args):                                                          # reference :405-407
         pass
 

@@ -184,6 +184,17 @@ def test_eval_kernels(ops, oracle):
     for i in (0, 17, 400, 2999):
         env.board = tiles_of(gp["board"][i]).reshape(4, 4)
         assert env._evaluate_pattern() == gp["pattern"][i]
+    from agents.beam_search_agent import BeamSearchAgent     # the agent's own per-board helpers (beam_search_agent.py:183-192, :271-373)
+    agent, gm = BeamSearchAgent(20, 30, seed=1), load_golden("moves.npz")
+    for i in (0, 5, 123, 1500, 3014):
+        t = tiles_of(g["board"][i]).reshape(4, 4)
+        assert agent._fast_evaluate(t) == g["fast"][i]
+        for p, name in enumerate(("early", "mid", "late")):
+            assert agent._evaluate_state(t, name) == g["full"][i, p]
+        assert ("early", "mid", "late").index(agent._determine_game_phase(int(t.max()))) == g["phase"][i]
+    for i in (0, 40, 700, 1514):
+        want = [bool((int(gm["agent_mask"][i]) >> a) & 1) for a in range(4)]
+        assert agent._check_valid_moves(tiles_of(gm["board"][i]).reshape(4, 4)) == want
 
 
 def test_pack_unpack_roundtrip(ops, oracle):
