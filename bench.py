@@ -259,7 +259,7 @@ def main():
         sc.keep_alive(boards, actions, out, scores, reward, flags)
 
     def steps_in_chains(t0, count):
-        sc.fork()
+        sc.fork()                   # (no-op if the chains are open already: the timed region opens them before its clock starts)
         lanes = [(call, sc.stream(c).cuda_stream) for c, call in enumerate(chain_calls)]
         for t in range(t0, t0 + count):
             for call, sp_ in lanes:
@@ -298,6 +298,8 @@ def main():
     o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     barrier()
+    if len(sc) > 1:
+        sc.fork()       # stream plumbing only (the side streams wait for the -- idle -- launch stream): no GPU work, like a graph's capture
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     o0.record()

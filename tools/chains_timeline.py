@@ -18,6 +18,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=
         if "step_kernel" not in row.get("Kernel_Name", ""):
             continue
         grid = int(row.get("Grid_Size") or row.get("Grid_Size_X") or 0)
+        if grid < (1 << 18):            # only the headline-sized launches (sub-batch chains and whole batches)
+            continue
         rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), grid, row.get("Queue_Id", "?"), row["Kernel_Name"]))
 rows.sort()
 if not rows:
@@ -33,6 +35,8 @@ for r in rows:
 bursts.append(cur)
 by = defaultdict(list)
 for b in bursts:
+    if len(b) < 4:
+        continue
     grids = sorted(set(r[2] for r in b))
     queues = sorted(set(r[3] for r in b))
     span = max(r[1] for r in b) - min(r[0] for r in b)
@@ -46,24 +50,32 @@ for b in bursts:
             busy2 += t - t_prev
         depth += dlt
         t_prev = t
-    boards = sum(r[2] for r in b)          # one lane per board: grid size (threads) = boards of the launch
-    by[(tuple(grids), len(queues), len(b))].append((span, busy1, busy2, boards, sum(r[1] - r[0] for r in b) / len(b)))
-print("%d step_kernel launches in %d bursts (%s)" % (len(rows), len(bursts), d))
-for (grids, nq, nl), v in sorted(by.items()):
-    if nl < 4:
-        continue
-    v.sort()
-    span, busy1, busy2, boards, avg = v[len(v) // 2]
-    steps = boards / (1 << 20)
-    print("launch sizes %s on %d queue(s), %d launches per burst, %d bursts: median burst first start -> last end %.1f us = %.2f us per Mi boards "
-          "(%.3f of 8 TB/s at 46 B per board); a launch lasts %.2f us on average; >= 1 launch in flight %.1f %% of the burst, >= 2 in flight %.1f %%"
-          % (list(grids), nq, nl, len(v), span / 1e3, span / 1e3 / steps, 46 * (1 << 20) / (span / steps) / 8000.0,
-             avg / 1e3, 100.0 * busy1 / span, 100.0 * busy2 / span))
+    steps = sum(r[2] for r in b) / float(1 << 20)          # one lane per board: grid size (threads) = boards of the launch
+    by[(tuple(grids), len(queues))].append((span / 1e3 / steps, sum(r[1] - r[0] for r in b) / len(b) / 1e3, 100.0 * busy1 / span,
+                                             100.0 * busy2 / span, len(b)))
+print("%d step_kernel launches of >= 262,144 boards in %d bursts (%s)" % (len(rows), len(bursts), d))
+print("per launch form: bursts, launches per burst (min..max), then MEDIANS over the bursts of: first start -> last end per Mi boards, the "
+      "duration of one launch, share of the burst with >= 1 / >= 2 launches in flight")
+for (grids, nq), v in sorted(by.items()):
+    per_mi = sorted(x[0] for x in v)[len(v) // 2]
+    print("  launches of %s boards on %d queue(s): %3d bursts of %d..%d launches: %6.2f us per Mi boards (%.3f of 8 TB/s at 46 B per board); "
+          "a launch lasts %5.2f us; >= 1 in flight %5.1f %%, >= 2 in flight %5.1f %%"
+          % (list(grids), nq, len(v), min(x[4] for x in v), max(x[4] for x in v), per_mi, 46 * (1 << 20) / (per_mi * 1e3) / 8000.0,
+             sorted(x[1] for x in v)[len(v) // 2], sorted(x[2] for x in v)[len(v) // 2], sorted(x[3] for x in v)[len(v) // 2]))
 if dump:
-    for b in bursts:
-        if len(b) >= 4 and len(set(r[3] for r in b)) > 1:
-            t0 = b[0][0]
-            print("first %d launches of a two-queue burst (start / end in us from the burst's first start, grid, queue):" % dump)
-            for r in b[:dump]:
-                print("   %8.2f %8.2f  grid %8d  queue %s" % ((r[0] - t0) / 1e3, (r[1] - t0) / 1e3, r[2], r[3]))
-            break
+    def overlap(b):
+        ev = sorted([(r[0], 1) for r in b] + [(r[1], -1) for r in b])
+        depth, t_prev, busy2 = 0, ev[0][0], 0
+        for t, dlt in ev:
+            if depth >= 2:
+                busy2 += t - t_prev
+            depth += dlt
+            t_prev = t
+        return busy2 / float(max(r[1] for r in b) - min(r[0] for r in b))
+    two = [b for b in bursts if len(b) >= 4 and len(set(r[3] for r in b)) > 1]
+    if two:
+        b = max(two, key=overlap)
+        t0 = b[0][0]
+        print("first %d launches of the two-queue burst with the largest overlap (start / end in us from the burst's first start, boards, queue):" % dump)
+        for r in b[:dump]:
+            print("   %8.2f %8.2f   %8d  queue %s" % ((r[0] - t0) / 1e3, (r[1] - t0) / 1e3, r[2], r[3]))
