@@ -375,21 +375,6 @@ def main():
         single_s = sum(reads[1:]) / 3.0
         del gs
 
-    # ---- the chain form past its start-up: the same launches, 100 steps in one burst (event pair / 100). The timed region above is
-    # K steps from an idle device, so at the driver's K = 20 its fork, join and first-launch latency (~30 us) weigh 1.5 us per step
-    steady_s = None
-    if len(sc) > 1:
-        reads = []
-        for _ in range(3):
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            c0.record()
-            steps_in_chains(W, 100)
-            c1.record()
-            torch.cuda.synchronize()
-            reads.append(c0.elapsed_time(c1) * 1e-3 / 100)
-        steady_s = sorted(reads)[1]
-
     # ---- kernel time of the timed region's launches (after the score exchange above: the extra launches below add to `scores`)
     # THE definition of roofline.frac (frozen in round 3): the HIP event pair around the timed region's own K launches / K.
     # With a hipGraph that pair also holds the replay's fixed cost (~8 us per replay: +0.4 us per launch at K = 20) and, from an
@@ -463,10 +448,6 @@ def main():
                      "frac_wall": n * STEP_BYTES_F32 / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": n * STEP_BYTES_F32, "algorithmic_bytes_per_step": n * STEP_BYTES_F32, "timing": timing,
                      "chains_equal_single_launch": chains_equal,
-                     "chains_100_step_burst": ({"kernel_us": steady_s * 1e6, "frac": n * STEP_BYTES_F32 / steady_s / 1e9 / HBM_PEAK_GBS,
-                                                "timing": "event pair around 100 steps of the same two-stream launches from an idle device / 100, "
-                                                          "median of three: the form without the K = 20 region's start-up share"}
-                                               if steady_s is not None else None),
                      "single_launch": {"kernel_us": (single_s if single_s is not None else kernel_s) * 1e6,
                                        "frac": n * STEP_BYTES_F32 / (single_s if single_s is not None else kernel_s) / 1e9 / HBM_PEAK_GBS,
                                        "frac_plain_launches": n * STEP_BYTES_F32 / plain_s / 1e9 / HBM_PEAK_GBS,
