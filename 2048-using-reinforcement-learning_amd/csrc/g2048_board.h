@@ -358,7 +358,13 @@ G2048_HD uint32_t spawn_prefix(Board &b, uint32_t h, bool enable = true, uint32_
     const uint32_t idx = ((h >> 16) * n) >> 16;
     // rank to match, broadcast to every byte; 0x7f (never a rank, and still < 0x80 for the flag arithmetic)
     // switches the spawn off
-    const uint32_t target = enable ? (idx + 1u) * ones : 0x7f7f7f7fu;
+    uint32_t t_on = (idx + 1u) * ones;
+#if defined(__HIPCC__)
+    // computed for every lane and then SELECTED: left to itself the compiler wraps these four instructions in an exec-mask region
+    // (s_and_saveexec .. s_or exec) in the middle of the kernel, which is a scheduling barrier for everything around it
+    asm volatile("" : "+v"(t_on));
+#endif
+    const uint32_t target = enable ? t_on : 0x7f7f7f7fu;
     const uint32_t h0 = zflag(p0 ^ target) & z0;
     const uint32_t h1 = zflag((p1 + c0 * ones) ^ target) & z1;
     const uint32_t h2 = zflag((p2 + c1 * ones) ^ target) & z2;
@@ -531,9 +537,19 @@ G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_
 G2048_HD uint32_t pair_count(const Board &b);
 G2048_HD bool game_over_counted(const Board &b, uint32_t n_empty)
 {
+#if defined(__HIPCC__)
+    // ONE wave-uniform branch around the pair count (taken when some lane of the wavefront holds a full board) instead of the
+    // nest of exec-mask regions the two early returns compile to: a full board is rare, and every exec region in the middle of
+    // the step is a scheduling barrier for the instructions around it
+    const bool full = n_empty == 0u;
+    uint32_t pairs = 1u;
+    if (__builtin_amdgcn_ballot_w64(full) != 0ull) pairs = pair_count(b);
+    return n_empty == 16u || (full && pairs == 0u);
+#else
     if (n_empty == 16u) return true;
     if (n_empty != 0u) return false;
     return pair_count(b) == 0u;
+#endif
 }
 
 // Game2048Env.step (environment/game_2048.py:170-210) for one board: move (:185), valid (:188),
