@@ -484,9 +484,16 @@ def main():
                                                 "than the memory one, so that is the bound named")
     if gather_ms is not None:
         import torch.distributed as tdist
+        planes = gdist.backends()
         result["allgather_scores_ms"] = gather_ms
         result["n_ranks_seen"] = tdist.get_world_size()
-        result["backend"] = tdist.get_backend()
+        # the data plane (all-gather of the scores, all-reduce of the metrics) is RCCL unless its probe failed on this node, in
+        # which case the same exchange was staged through the host over gloo and data_note says why; barriers and clock
+        # readings always travel over gloo (g2048/dist.py)
+        result["backend"] = planes["data"]
+        result["backend_control"] = planes["control"]
+        if planes.get("data_note"):
+            result["backend_note"] = "RCCL data plane unavailable, staged through the host over gloo: " + planes["data_note"]
         result["gathered_equals_single_gpu"] = True        # asserted above on rank 0
         # what the scaling curve is read against: every rank's own K-step time, their spread, and the recorded N = 1 figure
         result["per_rank_ms_per_step"] = [t / K * 1e3 for t in per_rank_s]
@@ -954,9 +961,7 @@ def main():
                               "cpu_beam_expansions_per_s": ((result.get("beam") or {}).get("cpu_baseline") or {}).get("value")}
         print(json.dumps(result))
     if world > 1:
-        import torch.distributed as dist
-        barrier()                       # rank 0 was still verifying / printing: leave together
-        dist.destroy_process_group()
+        gdist.shutdown()                # rank 0 was still verifying / printing: leave together
     return 0
 
 

@@ -241,3 +241,47 @@ def test_eight_rank_gloo_ragged_and_empty_shards(oracle, n_global, n_games):
         assert m[0] == n_global and m[1] == int(sc.sum()) and m[2] == int((fl & 1).sum())
         assert np.array_equal(rows, full), rank
         assert times == [10.0 + k for k in range(world)] and slowest == 17.0
+
+
+def _fallback_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), G2048_RCCL_PROBE_TIMEOUT_S="30")
+    os.environ.pop("G2048_DIST_BACKEND", None)
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from g2048 import dist as gdist
+    gdist.init("nccl", None)            # what bench.py asks for; there is no GPU here, so the RCCL probe cannot succeed
+    planes = gdist.backends()
+    lo, hi = gdist.shard(11, rank, world)
+    gathered = gdist.all_gather_scores(torch.arange(lo, hi, dtype=torch.int32))
+    m = torch.tensor([hi - lo, rank + 1], dtype=torch.int64)
+    gdist.reduce_metrics(m)
+    slowest = gdist.max_over_ranks(5.0 + rank)
+    q.put((rank, planes, gathered.tolist(), m.tolist(), slowest))
+    gdist.shutdown()
+
+
+def test_rccl_probe_failure_falls_back_to_gloo_on_every_rank():
+    """init("nccl") on a host where RCCL cannot run (this container has no GPU): the data plane's probe fails, the ranks agree
+    over the control plane, and every collective of the bench still works over gloo -- the multi-GPU bench line is produced
+    (with backend_note) instead of the job dying in its one post-timing collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=180) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, planes, gathered, m, slowest in res:
+        assert planes["control"] == "gloo" and planes["data"] == "gloo" and planes["data_note"], planes
+        assert gathered == list(range(11)) and m == [11, 3] and slowest == 6.0

@@ -26,7 +26,9 @@ CHILD = textwrap.dedent("""
     torch.cuda.set_device(dev)
     w, r, lr = gdist.init("nccl", dev)
     import torch.distributed as dist
-    assert dist.is_initialized() and dist.get_backend() == "nccl" and (w, r) == (1, 0)
+    # control plane gloo, data plane RCCL (probed at init; a fallback to host staging would show up here)
+    assert dist.is_initialized() and (w, r) == (1, 0)
+    assert gdist.backends() == {"control": "gloo", "data": "nccl", "data_note": None}, gdist.backends()
     n = 1 << 16
     boards = ops.synth_boards(n, seed=1, device=dev)
     actions = ops.synth_actions(n, seed=1, device=dev)
@@ -149,3 +151,24 @@ def test_a_failing_rank_takes_the_job_down():
     assert "injected failure on rank 1" in out.stderr
     assert not any(l.startswith("{") for l in out.stdout.splitlines()), "no result line from a failed job"
     assert took < 240, "the surviving rank waited %.0f s" % took
+
+
+def test_bench_two_ranks_on_one_card_fall_back_from_rccl_and_still_report():
+    """The driver's command shape (`python bench.py --gpus 2 ...`, backend "nccl" asked for) on a box where RCCL cannot form the
+    group -- here: both ranks share the one card, which RCCL refuses ("Duplicate GPU") --: the probe of the data plane fails, the
+    ranks agree over gloo to stage the one post-timing exchange through the host, and the job still ends 0 with the N = 2 line:
+    gathered scores equal to the one-GPU result, `backend` = gloo with a `backend_note` naming the RCCL error."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", G2048_RCCL_PROBE_TIMEOUT_S="60")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "G2048_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-beam",
+                          "--no-rollout", "--no-extra", "--no-cpu-baseline", "--no-evaluation"], env=env, capture_output=True, text=True,
+                         timeout=400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["gathered_equals_single_gpu"] is True
+    assert line["backend_control"] == "gloo"
+    if line["backend"] != "nccl":           # (a box whose RCCL accepts two ranks on one device would simply use it)
+        assert line["backend"] == "gloo" and "RCCL data plane unavailable" in line["backend_note"], line.get("backend_note")
+    assert len(line["per_rank_ms_per_step"]) == 2 and line["scaling"] == "weak"
