@@ -26,6 +26,7 @@ class BeamSearchAgent:
         self.device = torch.device(device)
         self.seed = random.getrandbits(63) if seed is None else int(seed)
         self._calls = 0
+        self._spawns = 0
         self._init_patterns()
 
     def _init_patterns(self):                                                           # reference :32-69
@@ -70,6 +71,33 @@ class BeamSearchAgent:
     def _evaluate_state(self, board, game_phase):                                       # reference :316-373
         phase = torch.tensor([("early", "mid", "late").index(game_phase)], dtype=torch.uint8, device=self.device)
         return float(ops.evaluate(self._codes(board), L.EVAL_FULL, phase).item())
+
+    def _calculate_corner_bonus(self, board):                                           # reference :375-385
+        return float(ops.evaluate(self._codes(board), L.EVAL_CORNER_BONUS).item())
+
+    def _calculate_merge_potential(self, board):                                        # reference :387-403
+        return float(ops.evaluate(self._codes(board), L.EVAL_MERGE_POTENTIAL).item())
+
+    def _one_board_op(self, board, op, action=0, index=0):
+        """g2048_env_step on a scratch copy of `board`: returns (tiles int32[4,4], score word, flags)."""
+        codes = self._codes(board)
+        score = torch.zeros(1, dtype=torch.int32, device=self.device)
+        record = torch.zeros(L.ENV_RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        ops.env_step(codes, score, record, self.seed, index, 0, action, op)
+        h = record.cpu().numpy()
+        return h[0:64].view(np.int32).reshape(4, 4).copy(), int(h[64:68].view(np.int32)[0]), int(h[68])
+
+    def _make_move(self, board, action):                                                # reference :194-258
+        """(new_board, score_gained, move_was_valid) with the reference's semantics: DOWN returns the 180-degree-rotated
+        result (:209-210 vs :251-253), and an action outside 1..3 slides LEFT (no pre / post transform applies to it)."""
+        a = int(action)
+        tiles, gained, flags = self._one_board_op(board, L.ENV_OP_MOVE_AGENT, a if a in (1, 2, 3) else 0)
+        return tiles.astype(np.asarray(board).dtype, copy=False), gained, bool(flags & L.FLAG_VALID)
+
+    def _add_random_tile(self, board):                                                  # reference :260-269: IN PLACE, returns None
+        tiles, _, _ = self._one_board_op(board, L.ENV_OP_SPAWN, index=self._spawns)
+        self._spawns += 1
+        board[...] = tiles.reshape(np.shape(board))
 
     def remember(self, *args):                                                          # reference :405-407
         pass

@@ -247,6 +247,17 @@ __global__ __launch_bounds__(64) void env_step_kernel(uint4 *board_inout, uint32
         flags = max_code(cur) << G2048_FLAG_MAXCODE_SHIFT;
     } else if (op == G2048_ENV_OP_PEEK) {                         // the record of the board as it is (after `board` was assigned)
         flags = (max_code(cur) << G2048_FLAG_MAXCODE_SHIFT) | (game_over(cur) ? G2048_FLAG_DONE : 0u);
+    } else if (op == G2048_ENV_OP_MOVE || op == G2048_ENV_OP_MOVE_AGENT) {
+        // _execute_move (:97-114) / BeamSearchAgent._make_move (agents/beam_search_agent.py:194-258): the move alone
+        uint32_t gain = 0u;
+        Board moved = cur;
+        if (action <= 3u) moved = op == G2048_ENV_OP_MOVE ? move_env(cur, action, gain) : move_agent(cur, action, gain, false);
+        const bool changed = !same(moved, cur);
+        cur = moved; sc += gain;
+        flags = (max_code(cur) << G2048_FLAG_MAXCODE_SHIFT) | (changed ? G2048_FLAG_VALID : 0u) | (game_over(cur) ? G2048_FLAG_DONE : 0u);
+    } else if (op == G2048_ENV_OP_SPAWN) {                        // add_new_tile (:59-67) / _add_random_tile (agent :260-269)
+        const uint32_t n_empty = spawn_prefix(cur, rng_draw(k0, k1, id, 1u));
+        flags = (max_code(cur) << G2048_FLAG_MAXCODE_SHIFT) | (n_empty ? G2048_FLAG_VALID : 0u) | (game_over(cur) ? G2048_FLAG_DONE : 0u);
     } else {                                                      // :170-210; an action outside 0..3 moves nothing (:97-114)
         const uint32_t *d = kDirTable + 8u * (action & 3u);
         const StepOut o = step_board_sel_noop(cur, DirSel{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]}, action > 3u,
@@ -462,6 +473,8 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const uint4 *__restrict__ 
     else if (KIND == G2048_EVAL_PPO_HEURISTIC) v = eval_ppo_heuristic(b);
     else if (KIND == G2048_EVAL_PPO_SHAPING) v = eval_ppo_shaping(b, 0.0);
     else if (KIND == G2048_EVAL_PATTERN) v = eval_pattern(b);
+    else if (KIND == G2048_EVAL_CORNER_BONUS) v = (double)max_corner_code(b) * 2.0;          // log2(max corner) * 2.0, 0 if none
+    else if (KIND == G2048_EVAL_MERGE_POTENTIAL) v = (double)merge_potential(b);            // a sum of small integers: exact in any order
     else v = eval_monotonicity(b, KIND - G2048_EVAL_MONO_PP);
     out[i] = v;
 }
@@ -735,7 +748,7 @@ int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, ui
 {
     if (!board_inout || !score_inout || !record_out) return fail(G2048_ERR_ARG, "g2048_env_step: null pointer");
     if (!aligned16(board_inout) || !aligned4(score_inout) || !aligned16(record_out)) return fail(G2048_ERR_ARG, "g2048_env_step: misaligned pointer");
-    if (op > G2048_ENV_OP_PEEK) return fail(G2048_ERR_ARG, "g2048_env_step: unknown op %u", op);
+    if (op > G2048_ENV_OP_MOVE_AGENT) return fail(G2048_ERR_ARG, "g2048_env_step: unknown op %u", op);
     const Keys k = rng_keys(seed, op == G2048_ENV_OP_RESET ? DOM_RESET : DOM_STEP, index);
     hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint4 *>(board_inout),
                        score_inout, action, op, static_cast<EnvRecord *>(record_out), k.k0, k.k1, board_id);
@@ -893,6 +906,8 @@ int g2048_eval(const void *boards, int kind, const uint8_t *phase_or_null, doubl
         G2048_EVAL_CASE(G2048_EVAL_MONO_MM)
         G2048_EVAL_CASE(G2048_EVAL_PPO_SHAPING)
         G2048_EVAL_CASE(G2048_EVAL_PATTERN)
+        G2048_EVAL_CASE(G2048_EVAL_CORNER_BONUS)
+        G2048_EVAL_CASE(G2048_EVAL_MERGE_POTENTIAL)
 #undef G2048_EVAL_CASE
         default: return fail(G2048_ERR_ARG, "g2048_eval: unknown kind %d", kind);
     }

@@ -48,6 +48,7 @@ class Game2048Env:
         self._h = self._host.numpy()
         self._t = 0
         self._epoch = 0
+        self._spawns = 0            # add_new_tile() calls made directly (their draws are a stream of their own)
         self._mask = None           # valid-move mask of the current board, if the last record still describes it
         self.highest_tile = 0
         self.reset()
@@ -118,6 +119,21 @@ class Game2048Env:
             "valid_move": bool(flags & L.FLAG_VALID),
             "highest_tile": self.highest_tile,
         }
+
+    # -- the pieces of a step, for scripts that drive them directly (one small launch each, as step()) -----------------
+    def add_new_tile(self):                                    # reference :59-67
+        """A 2 (90 %) or a 4 on a random empty cell; nothing on a full board. The draw is (seed, STEP, k, counter 1) for the
+        k-th direct call -- never a draw step() itself uses."""
+        self._run(L.ENV_OP_SPAWN, self._spawns)
+        self._spawns += 1
+
+    def _execute_move(self, action):                           # reference :97-114: the move alone, no new tile
+        a = int(action)
+        self._run(L.ENV_OP_MOVE, 0, a if a in (0, 1, 2, 3) else 255)
+
+    def _move_left(self):                                      # reference :116-168
+        flags, _ = self._run(L.ENV_OP_MOVE, 0, 0)
+        return bool(flags & L.FLAG_VALID)
 
     def simulate_move(self, state, action):                    # reference :341-387
         """All (next_state, reward, done) successors of `action` on `state`, as the reference lists them

@@ -18,7 +18,8 @@ ABI_VERSION = 4
 FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
 STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS, STEP_NOOP_ACTIONS = 0x01, 0x02, 0x04, 0x08
 VALID_ENV, VALID_AGENT = 0, 1
-EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING, EVAL_PATTERN = range(9)
+(EVAL_FAST, EVAL_FULL, EVAL_PPO_HEURISTIC, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING, EVAL_PATTERN,
+ EVAL_CORNER_BONUS, EVAL_MERGE_POTENTIAL) = range(11)
 BEAM_FIXED_DOWN = 0x01
 BEAM_RANK_BY_COUNTING = 0x04
 PLAY_ONE_PHASE = 0x02
@@ -26,7 +27,7 @@ BEAM_MAX_WIDTH = 128
 KEYBLOCK_WORDS = 16
 ROLLOUT_OBS_SHIFT, OBS_F32, OBS_F16, OBS_BF16 = 4, 0, 1, 2
 SEEN_SLOT_BYTES = 32
-ENV_RECORD_BYTES, ENV_OP_STEP, ENV_OP_RESET, ENV_OP_PEEK = 80, 0, 1, 2
+ENV_RECORD_BYTES, ENV_OP_STEP, ENV_OP_RESET, ENV_OP_PEEK, ENV_OP_MOVE, ENV_OP_SPAWN, ENV_OP_MOVE_AGENT = 80, 0, 1, 2, 3, 4, 5
 
 _vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {

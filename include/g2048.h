@@ -94,7 +94,9 @@ enum {
     G2048_EVAL_MONO_MM = 6,    /*                        (-1, -1) */
     G2048_EVAL_PPO_SHAPING = 7,/* the pure per-transition terms of PPOAgent.remember, ppo_agent.py:253-266:
                                   0.1 * sum(log2(top-4 tiles)) + 0.3 * evaluate_heuristic (stateful terms excluded) */
-    G2048_EVAL_PATTERN = 8     /* Game2048Env._evaluate_pattern  game_2048.py:313-339 (snake / corner weights on tile values) */
+    G2048_EVAL_PATTERN = 8,    /* Game2048Env._evaluate_pattern  game_2048.py:313-339 (snake / corner weights on tile values) */
+    G2048_EVAL_CORNER_BONUS = 9,     /* BeamSearchAgent._calculate_corner_bonus     beam_search_agent.py:375-385 (unweighted) */
+    G2048_EVAL_MERGE_POTENTIAL = 10  /* BeamSearchAgent._calculate_merge_potential  beam_search_agent.py:387-403 (unweighted) */
 };
 
 /* opts of g2048_beam_get_action */
@@ -279,11 +281,21 @@ G2048_API int g2048_replay_games(const void *boards0, const uint32_t *score0_or_
  * of pinned, device-visible host memory, 16-byte aligned -- receives everything the host mirrors of the env need, so that an
  * iteration costs one launch and one copy: [0,64) the state as int32 tile values (get_state, :50-57), [64,68) int32 score,
  * [68] the flags byte (DONE / VALID / max code), [69] the valid-move mask of the NEW state (get_valid_moves, :69-95, for the
- * next iteration), [72,80) the f64 reward (:212-277; 0.0 for RESET / PEEK). */
+ * next iteration), [72,80) the f64 reward (:212-277; 0.0 for every op but STEP).
+ * The pieces of a step as ops of their own (the reference's methods of the same names, for callers that drive them directly):
+ * op MOVE = Game2048Env._execute_move(action) (:97-114; action 0 is _move_left, :116-168): the slide / merge alone -- score +=
+ * merged tiles, no spawn; flags: VALID = the board changed, DONE = is_game_over() of the result. op MOVE_AGENT = the same with
+ * BeamSearchAgent._make_move's semantics (agents/beam_search_agent.py:194-258: DOWN returns rot180 of the true result); with
+ * *score_inout = 0 before the call the record's score is its merge_score. op SPAWN = Game2048Env.add_new_tile() (:59-67) /
+ * BeamSearchAgent._add_random_tile (:260-269): one 2 / 4 on an empty cell by the draw (seed, STEP, index, board_id, counter 1)
+ * -- counter 0 is the step's own spawn --, nothing on a full board; flags: VALID = a tile was placed. */
 #define G2048_ENV_RECORD_BYTES 80
 #define G2048_ENV_OP_STEP  0u
 #define G2048_ENV_OP_RESET 1u
 #define G2048_ENV_OP_PEEK  2u
+#define G2048_ENV_OP_MOVE  3u
+#define G2048_ENV_OP_SPAWN 4u
+#define G2048_ENV_OP_MOVE_AGENT 5u
 G2048_API int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
                    uint64_t index, uint64_t board_id, void *stream);
 

@@ -367,6 +367,31 @@ double g2048o_fast_eval(const int32_t b[16])
     return ((empty_score + max_score) + (double)corner_score) + (double)(merge_score * 2);
 }
 
+/* agents/beam_search_agent.py:375-385 (_calculate_corner_bonus): log2 of the largest corner times 2.0, 0 if all four are empty */
+double g2048o_corner_bonus(const int32_t b[16])
+{
+    const int32_t (*g)[4] = (const int32_t (*)[4])b;
+    int32_t max_corner = g[0][0];
+    if (g[0][3] > max_corner) max_corner = g[0][3];
+    if (g[3][0] > max_corner) max_corner = g[3][0];
+    if (g[3][3] > max_corner) max_corner = g[3][3];
+    return max_corner <= 0 ? 0.0 : log2((double)max_corner) * 2.0;
+}
+
+/* agents/beam_search_agent.py:387-403 (_calculate_merge_potential): sum of log2 over equal non-zero neighbours, rows then columns */
+double g2048o_merge_potential(const int32_t b[16])
+{
+    const int32_t (*g)[4] = (const int32_t (*)[4])b;
+    double mp = 0.0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (g[i][j] > 0 && g[i][j] == g[i][j + 1]) mp += log2((double)g[i][j]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (g[i][j] > 0 && g[i][j] == g[i + 1][j]) mp += log2((double)g[i][j]);
+    return mp;
+}
+
 /* agents/beam_search_agent.py:316-403 (_evaluate_state, _calculate_corner_bonus,
  * _calculate_merge_potential), f64, left-to-right as written.               */
 double g2048o_full_eval(const int32_t b[16], int phase)
@@ -383,19 +408,8 @@ double g2048o_full_eval(const int32_t b[16], int phase)
     if (mx >= 512) max_score *= 1.2;
     if (mx >= 1024) max_score *= 1.5;
     if (mx >= 2048) max_score *= 2.0;
-    int32_t max_corner = g[0][0];
-    if (g[0][3] > max_corner) max_corner = g[0][3];
-    if (g[3][0] > max_corner) max_corner = g[3][0];
-    if (g[3][3] > max_corner) max_corner = g[3][3];
-    double corner_bonus = (max_corner <= 0 ? 0.0 : log2((double)max_corner) * 2.0) * w[2];
-    double mp = 0.0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 3; ++j)
-            if (g[i][j] > 0 && g[i][j] == g[i][j + 1]) mp += log2((double)g[i][j]);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 4; ++j)
-            if (g[i][j] > 0 && g[i][j] == g[i + 1][j]) mp += log2((double)g[i][j]);
-    double merge_potential = mp * w[3];
+    double corner_bonus = g2048o_corner_bonus(b) * w[2];             /* :358-359 */
+    double merge_potential = g2048o_merge_potential(b) * w[3];       /* :362-363 */
     double snake = 0.0;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
@@ -975,7 +989,7 @@ void g2048o_valid_moves_batch(const uint8_t *boards, uint8_t *mask4, size_t n, i
 }
 
 /* kind: 0 fast, 1 full (phase[i] in 0..2), 2 ppo heuristic, 3..6 monotonicity
- * (+,+) (+,-) (-,+) (-,-), 7 pure PPO shaping terms (reward_in = 0).          */
+ * (+,+) (+,-) (-,+) (-,-), 7 pure PPO shaping terms (reward_in = 0), 8 pattern, 9 corner bonus, 10 merge potential. */
 /* environment/game_2048.py:313-339 (_evaluate_pattern; unused by the reference itself): np.sum(board * snake) / 100.0 and
  * np.sum(board * corner) / 100.0 -- the int products summed in int64, the float products (weights down to 0.25: exact binary
  * fractions, so numpy's pairwise order and this sequential one give the same sum) in float64 -- then max(). */
@@ -1006,6 +1020,8 @@ void g2048o_eval_batch(const uint8_t *boards, int kind, const uint8_t *phase, do
         case 5: v = g2048o_monotonicity(b, -1, 1); break;
         case 6: v = g2048o_monotonicity(b, -1, -1); break;
         case 8: v = g2048o_pattern(b); break;
+        case 9: v = g2048o_corner_bonus(b); break;
+        case 10: v = g2048o_merge_potential(b); break;
         default: v = g2048o_ppo_shaping(b, 0.0); break;
         }
         out[i] = v;

@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libg2048_oracle.so")
 
 DOM_STEP, DOM_RESET, DOM_BEAM, DOM_SYNTH_BOARD, DOM_SYNTH_ACTION, DOM_EPISODE, DOM_POLICY, DOM_SIMULATE = 1, 2, 3, 4, 5, 6, 7, 8
-EVAL_FAST, EVAL_FULL, EVAL_PPO, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING, EVAL_PATTERN = range(9)
+(EVAL_FAST, EVAL_FULL, EVAL_PPO, EVAL_MONO_PP, EVAL_MONO_PM, EVAL_MONO_MP, EVAL_MONO_MM, EVAL_PPO_SHAPING, EVAL_PATTERN,
+ EVAL_CORNER_BONUS, EVAL_MERGE_POTENTIAL) = range(11)
 
 
 def build(force=False):

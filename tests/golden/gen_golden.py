@@ -721,6 +721,21 @@ def gen_pattern():
     print("pattern", pool.shape[0])
 
 
+def gen_eval_parts():
+    """BeamSearchAgent._calculate_corner_bonus (:375-385) and _calculate_merge_potential (:387-403) on their own -- the two
+    terms _evaluate_state weights -- on the boards of eval_scores.npz."""
+    pool = np.load(os.path.join(HERE, "eval_scores.npz"))["board"]
+    agent = BeamSearchAgent()
+    corner = np.zeros(pool.shape[0], np.float64)
+    merge = np.zeros(pool.shape[0], np.float64)
+    for i in range(pool.shape[0]):
+        g = tiles_of(pool[i]).reshape(4, 4)
+        corner[i] = agent._calculate_corner_bonus(g.copy())
+        merge[i] = agent._calculate_merge_potential(g.copy())
+    np.savez_compressed(os.path.join(HERE, "eval_parts.npz"), board=pool, corner_bonus=corner, merge_potential=merge)
+    print("eval_parts", pool.shape[0], "boards with a merge:", int((merge > 0).sum()), "without a corner tile:", int((corner == 0).sum()))
+
+
 def gen_checkpoint():
     """The beam agent's checkpoint format (agents/beam_search_agent.py:413-478): the text of the reference-held
     checkpoints/BeamSearchAgent_*.pth files (JSON despite the name) and README files, and what the reference's own
@@ -758,8 +773,8 @@ def gen_checkpoint():
 def main():
     if "--only" in sys.argv:
         what = sys.argv[sys.argv.index("--only") + 1]
-        if what in ("pattern", "checkpoint", "games"):
-            {"pattern": gen_pattern, "checkpoint": gen_checkpoint, "games": gen_games}[what]()
+        if what in ("pattern", "checkpoint", "games", "eval_parts"):
+            {"pattern": gen_pattern, "checkpoint": gen_checkpoint, "games": gen_games, "eval_parts": gen_eval_parts}[what]()
             return
         if what == "step_noop":
             rng = np.random.default_rng(1)
@@ -828,6 +843,7 @@ def main():
     gen_step_noop(np.concatenate([random_code_boards(rng2, 600, 0.30, 11), random_code_boards(rng2, 300, 0.0, 3),
                                   random_code_boards(rng2, 300, 0.6, 17)]).astype(np.uint8))
     gen_pattern()
+    gen_eval_parts()
     gen_checkpoint()
     gen_games()
     print("done in %.1fs" % (time.time() - t0))

@@ -101,6 +101,7 @@ void hs_eval(const uint8_t *in, int kind, const uint8_t *phase, double *out, siz
         out[i] = kind == 0 ? eval_fast(b)
                : kind == 1 ? eval_full(b, phase ? phase[i] : phase_of(max_code(b), 512u, 1024u))
                : kind == 2 ? eval_ppo_heuristic(b) : kind == 7 ? eval_ppo_shaping(b, 0.0) : kind == 8 ? eval_pattern(b)
+               : kind == 9 ? (double)max_corner_code(b) * 2.0 : kind == 10 ? (double)merge_potential(b)
                : eval_monotonicity(b, kind - 3);
     }
 }

@@ -222,7 +222,7 @@ def test_round4_entry_points_validate_without_device(built):
     assert L.g2048_env_step(None, None, 0, 0, None, 0, 0, 0, None) == -1
     buf = (C.c_uint8 * 256)()
     base = (C.addressof(buf) + 15) & ~15
-    assert L.g2048_env_step(base, base + 16, 0, 3, base + 32, 0, 0, 0, None) == -1 and b"unknown op" in L.g2048_last_error()
+    assert L.g2048_env_step(base, base + 16, 0, 6, base + 32, 0, 0, 0, None) == -1 and b"unknown op" in L.g2048_last_error()      # ops 0..5 exist
     assert L.g2048_env_step(base + 1, base + 16, 0, 0, base + 32, 0, 0, 0, None) == -1 and b"misaligned" in L.g2048_last_error()
     args = [base, 0, base, base, base, 0, base, base, 100, 200, 0, 0, base, base, base, base, base, base, None, None]
     assert L.g2048_minibatch_gather(*args) == -1 and b"without replacement" in L.g2048_last_error()          # batch > n

@@ -179,6 +179,11 @@ def test_eval_kernels(ops, oracle):
     gp = load_golden("pattern.npz")                     # Game2048Env._evaluate_pattern (game_2048.py:313-339), f64 ==
     assert np.array_equal(host(ops.evaluate(dev(gp["board"]), L.EVAL_PATTERN)), gp["pattern"])
     assert np.array_equal(host(ops.evaluate(big, L.EVAL_PATTERN)), oracle.eval_batch(hb, oracle.EVAL_PATTERN))
+    ge = load_golden("eval_parts.npz")                  # the two terms _evaluate_state weights, on their own (:375-403)
+    assert np.array_equal(host(ops.evaluate(dev(ge["board"]), L.EVAL_CORNER_BONUS)), ge["corner_bonus"])
+    assert np.array_equal(host(ops.evaluate(dev(ge["board"]), L.EVAL_MERGE_POTENTIAL)), ge["merge_potential"])
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_CORNER_BONUS)), oracle.eval_batch(hb, oracle.EVAL_CORNER_BONUS))
+    assert np.array_equal(host(ops.evaluate(big, L.EVAL_MERGE_POTENTIAL)), oracle.eval_batch(hb, oracle.EVAL_MERGE_POTENTIAL))
     from environment.game_2048 import Game2048Env       # ... and through the drop-in class
     env = Game2048Env(seed=3)
     for i in (0, 17, 400, 2999):
@@ -752,3 +757,68 @@ def test_chains_inside_one_hipgraph(ops):
         torch.cuda.synchronize()
         for x, y in zip(_env_state(e1), _env_state(e2)):
             assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_step_pieces_as_env_ops_and_drop_in_methods(ops, oracle):
+    """The pieces of a step driven directly, as the reference's classes allow: Game2048Env._execute_move / _move_left /
+    add_new_tile (game_2048.py:97-168, :59-67) and BeamSearchAgent._make_move / _add_random_tile / _calculate_corner_bonus /
+    _calculate_merge_potential (beam_search_agent.py:194-269, :375-403) -- g2048_env_step ops MOVE / MOVE_AGENT / SPAWN and two
+    g2048_eval kinds underneath -- against what the REAL reference returned for the same boards (moves.npz, eval_parts.npz) and
+    against the oracle for the spawn."""
+    from g2048 import _lib as L
+    from environment.game_2048 import Game2048Env
+    from agents.beam_search_agent import BeamSearchAgent
+    g, ge = load_golden("moves.npz"), load_golden("eval_parts.npz")
+    env, agent = Game2048Env(seed=77), BeamSearchAgent(20, 30, seed=78)
+    rng = np.random.default_rng(4)
+    rows = np.concatenate([np.arange(40), rng.choice(g["board"].shape[0], 160, replace=False)])
+    for i in rows:
+        t = tiles_of(g["board"][i]).reshape(4, 4)
+        for a in range(4):
+            env.board, env.score = t.copy(), 100
+            env._execute_move(a)                                                   # :97-114
+            assert np.array_equal(env.board.reshape(-1), tiles_of(g["env_board"][i, a])), (i, a)
+            assert int(env.score) == 100 + int(g["env_gain"][i, a])
+            assert env.get_valid_moves() == [bool((int(oracle.env_valid_mask(env.board.reshape(-1))) >> k) & 1) for k in range(4)]
+            nb, sc, valid = agent._make_move(t.copy(), a)                         # :194-258, DOWN quirk included
+            assert np.array_equal(nb.reshape(-1), tiles_of(g["agent_board"][i, a])), (i, a)
+            assert sc == int(g["agent_score"][i, a]) and valid == bool(g["agent_valid"][i, a])
+        env.board = t.copy()
+        assert env._move_left() == (not np.array_equal(g["env_board"][i, 0], g["board"][i]))      # :116-168 returns `changed`
+        assert np.array_equal(env.board.reshape(-1), tiles_of(g["env_board"][i, 0]))
+    assert not np.array_equal(g["agent_board"][rows, 3], g["env_board"][rows, 3])                 # (the quirk is in the sample)
+    # an action outside 0..3: nothing moves in the env (:97-114); the agent's _make_move slides LEFT (no transform applies)
+    t = tiles_of(g["board"][5]).reshape(4, 4)
+    env.board = t.copy(); env._execute_move(7)
+    assert np.array_equal(env.board, t)
+    assert np.array_equal(agent._make_move(t.copy(), 9)[0].reshape(-1), tiles_of(g["agent_board"][5, 0]))
+    # add_new_tile / _add_random_tile: the k-th direct call takes the draw (seed, STEP, k, board 0, counter 1)
+    for k, i in enumerate(rows[:60]):
+        t = tiles_of(g["board"][i]).reshape(4, 4)
+        k0, k1 = oracle.rng_keys(env.seed, 1, env._spawns)
+        h = oracle.rng_draw(k0, k1, 0, 1)
+        want = t.reshape(-1).copy()
+        empty = np.flatnonzero(want == 0)
+        if empty.size:
+            want[empty[oracle.draw_index(h, empty.size)]] = 4 if oracle.draw_is4(h) else 2
+        env.board = t.copy()
+        env.add_new_tile()                                                         # :59-67
+        assert np.array_equal(env.board.reshape(-1), want), i
+        k0, k1 = oracle.rng_keys(agent.seed, 1, agent._spawns)
+        h = oracle.rng_draw(k0, k1, 0, 1)
+        want = t.reshape(-1).copy()
+        if empty.size:
+            want[empty[oracle.draw_index(h, empty.size)]] = 4 if oracle.draw_is4(h) else 2
+        mine = t.copy()
+        assert agent._add_random_tile(mine) is None and np.array_equal(mine.reshape(-1), want)   # :260-269, in place
+    full = np.full((4, 4), 2, np.int32); full[::2, ::2] = 4; full[1::2, 1::2] = 4
+    env.board = full.copy(); env.add_new_tile()
+    assert np.array_equal(env.board, full)                                         # a full board takes no tile
+    for i in (0, 9, 77, 1500, 3014):
+        t = tiles_of(ge["board"][i]).reshape(4, 4)
+        assert agent._calculate_corner_bonus(t) == ge["corner_bonus"][i]           # :375-385
+        assert agent._calculate_merge_potential(t) == ge["merge_potential"][i]     # :387-403
+    # the raw ops refuse what they do not know
+    b = dev(g["board"][:1].copy()); sc = torch.zeros(1, dtype=torch.int32, device=DEV); rec = torch.zeros(80, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.env_step(b, sc, rec, 1, 0, 0, 0, 6)

@@ -177,6 +177,11 @@ def test_eval_vs_golden_and_oracle(hs, oracle):
     gp = load_golden("pattern.npz")                 # Game2048Env._evaluate_pattern (integer formulation vs the reference's floats)
     assert np.array_equal(ev(np.ascontiguousarray(gp["board"]), 8), gp["pattern"])
     assert np.array_equal(ev(rb, 8), oracle.eval_batch(rb, oracle.EVAL_PATTERN))
+    ge = load_golden("eval_parts.npz")              # _calculate_corner_bonus / _calculate_merge_potential on their own
+    gb = np.ascontiguousarray(ge["board"])
+    assert np.array_equal(ev(gb, 9), ge["corner_bonus"]) and np.array_equal(ev(gb, 10), ge["merge_potential"])
+    assert np.array_equal(ev(rb, 9), oracle.eval_batch(rb, oracle.EVAL_CORNER_BONUS))
+    assert np.array_equal(ev(rb, 10), oracle.eval_batch(rb, oracle.EVAL_MERGE_POTENTIAL))
     assert np.array_equal(ev(rb, 0), oracle.eval_batch(rb, oracle.EVAL_FAST))
     for ph in range(3):
         pa = np.full(rb.shape[0], ph, np.uint8)

@@ -102,6 +102,10 @@ def test_eval_scores(oracle):
     assert np.array_equal(oracle.eval_batch(b, oracle.EVAL_PPO_SHAPING), g["ppo_shaping"])       # remember() pure terms
     gp = load_golden("pattern.npz")                                                              # Game2048Env._evaluate_pattern
     assert np.array_equal(oracle.eval_batch(gp["board"], oracle.EVAL_PATTERN), gp["pattern"])
+    ge = load_golden("eval_parts.npz")              # BeamSearchAgent._calculate_corner_bonus (:375-385) / _calculate_merge_potential (:387-403)
+    assert np.array_equal(oracle.eval_batch(ge["board"], oracle.EVAL_CORNER_BONUS), ge["corner_bonus"])
+    assert np.array_equal(oracle.eval_batch(ge["board"], oracle.EVAL_MERGE_POTENTIAL), ge["merge_potential"])
+    assert (ge["corner_bonus"] == 0).any() and (ge["merge_potential"] > 0).any()
     assert np.array_equal(oracle.obs_batch(b).view(np.uint32), g["normalize"].view(np.uint32))   # f32 bits
     for i in range(0, b.shape[0], 50):
         t = tiles_of(b[i])
