@@ -61,11 +61,26 @@ __device__ __forceinline__ void dir_table_to_lds(uint4 *s_dir)
     reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];                    // no exec masking, no branch
 }
 
+// The same in two halves, so that a kernel can put its own loads BETWEEN the table word's load and its LDS write: the write has
+// to wait for the word, and loads issued only after it would start a second memory round trip at the head of every wavefront
+// (the compiler does not move a global load up across the write). Every lane of the wavefront must run both halves.
+__device__ __forceinline__ uint32_t dir_table_word()
+{
+    return kDirTable[threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u)];
+}
+
+__device__ __forceinline__ void dir_table_store(uint4 *s_dir, uint32_t word)
+{
+    reinterpret_cast<uint32_t *>(s_dir)[threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u)] = word;
+}
+
 __device__ __forceinline__ DirSel dir_sel(const uint4 *s_dir, uint32_t action)
 {
     const uint4 i = s_dir[2u * action], o = s_dir[2u * action + 1u];
     return DirSel{i.x, i.y, i.z, i.w, o.x, o.y, o.z, o.w};
 }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: volatile 16-byte loads stay ONE global_load_dwordx4)
 
 __device__ __forceinline__ Board load_board(const uint4 *p, size_t i)
 {
@@ -86,14 +101,17 @@ __device__ __forceinline__ void store_board(uint4 *p, size_t i, const Board &b)
 // of a wave touches 64 consecutive boards (1 KiB per wave-instruction).
 // NOOP_ACTIONS: action bytes above 3 move nothing, as in the reference (drop-in class); otherwise the low two bits count
 template <bool REWARD_F64, bool AUTO_RESET, int B, int BLOCK, bool RANDOM_ACTIONS = false, bool NOOP_ACTIONS = false>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,       // may alias boards_out
+__global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *__restrict__ keyblock,
+                                                     const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
-                                                     uint4 *boards_out,
                                                      uint32_t *__restrict__ score,
+                                                     uint64_t id_base, uint32_t k0, uint32_t k1,
+                                                     // (the first 14 dwords -- everything the head of a wavefront needs before its loads
+                                                     // can go out -- arrive preloaded in SGPRs: -amdgpu-kernarg-preload-count, g2048/_build.py)
+                                                     uint4 *boards_out,
                                                      void *__restrict__ reward_out,
                                                      uint8_t *__restrict__ flags_out,
-                                                     uint32_t k0, uint32_t k1, uint32_t e0, uint32_t e1,
-                                                     uint64_t id_base, size_t n, const uint32_t *__restrict__ keyblock,
+                                                     uint32_t e0, uint32_t e1,
                                                      uint32_t a0 = 0, uint32_t a1 = 0)
 {
     // Streaming launches (two boards per lane, from 4 Mi boards on): a new wavefront issues its loads ahead of the arithmetic of
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
-    dir_table_to_lds(s_dir);
+    const uint32_t dir_word = dir_table_word();                   // (stored to LDS below, once the lane's own loads are on their way)
     // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
     const size_t block0 = (size_t)blockIdx.x * (BLOCK * B);
     const uint4 *bin = boards_in + block0;
@@ -115,23 +133,24 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
     double *rw64 = static_cast<double *>(reward_out) + block0;
     const bool full = block0 + (size_t)(BLOCK * B) <= n;          // wave-uniform: every lane of the block is in range
     const uint32_t lim = full ? (uint32_t)(BLOCK * B) : (uint32_t)(n - block0);
-    if (B == 1 && !(full || threadIdx.x < lim)) return;       // one exec region for the whole body instead of two
+    // Every lane loads -- the lanes past the end of a ragged last block a clamped (valid) index whose data they drop -- so that
+    // the loads need no exec region and go out BEFORE the direction table's LDS write waits for its word: one memory round trip
+    // at the head of a wavefront, not two.
     Board prev[B];
     uint32_t action[B], sc[B];
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
-        if (full || j < lim) {
-            prev[k] = load_board(bin, j);
-            if (!RANDOM_ACTIONS) action[k] = act[j];
-            sc[k] = scp[j];
-        }
+        const uint32_t j = min(threadIdx.x + (uint32_t)k * BLOCK, lim - 1u);
+        prev[k] = load_board(bin, j);
+        if (!RANDOM_ACTIONS) action[k] = act[j];
+        sc[k] = scp[j];
     }
+    dir_table_store(s_dir, dir_word);
     if (B > 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < B; ++k) {
         const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
-        if (!(full || j < lim)) break;
+        if (B > 1 && !(full || j < lim)) break;
         const uint64_t id = id_base + block0 + j;
         if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
         const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u))
@@ -144,6 +163,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const uint4 *boards_in,    
                 s = 0u;
             }
         }
+        // B == 1: the lanes past the end of a ragged last block ran the arithmetic on their clamped loads (no exec region around
+        // the body: the compiler would sink the loads into it, behind the table's write); they store nothing
+        if (B == 1 && !(full || j < lim)) return;
         store_board(bout, j, cur);
         scp[j] = s;
         if (REWARD_F64) rw64[j] = o.reward;
@@ -660,14 +682,14 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     // both loads in flight before the first is computed, stream 4-5 % faster (profiles/r02_step_tune.txt)
     const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : (n >= ((size_t)1 << 22) ? 2 : kStepBoardsPerLane);
 #define G2048_LAUNCH_STEP(F, A, BB) \
-    hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, in, actions, out, \
-                       score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
+    hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, n, keyblock, in, actions, \
+                       score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
 #define G2048_LAUNCH_STEP_B(F, A) \
     do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else G2048_LAUNCH_STEP(F, A, 2); } while (0)
     if (opts & G2048_STEP_NOOP_ACTIONS) {            // reference semantics for action values outside 0..3 (drop-in class)
         if (random_actions) return fail(G2048_ERR_ARG, "g2048_step: NOOP_ACTIONS needs explicit actions");
 #define G2048_LAUNCH_NOOP(F, A) hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, \
-                           in, actions, out, score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock)
+                           n, keyblock, in, actions, score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
         if (f64 && ar) G2048_LAUNCH_NOOP(true, true); else if (f64) G2048_LAUNCH_NOOP(true, false);
         else if (ar) G2048_LAUNCH_NOOP(false, true); else G2048_LAUNCH_NOOP(false, false);
 #undef G2048_LAUNCH_NOOP
@@ -676,8 +698,8 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     if (random_actions) {           // uniform actions drawn in the kernel: (seed, SYNTH_ACTION, step_index, board id) >> 30
         const Keys ak = rng_keys(seed, DOM_SYNTH_ACTION, step_index);
 #define G2048_LAUNCH_RANDOM(F, A) \
-        hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, in, actions, out, \
-                           score_inout, reward_out, flags_out, k.k0, k.k1, e.k0, e.k1, board_id_base, n, keyblock, ak.k0, ak.k1)
+        hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, n, keyblock, in, actions, \
+                           score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1, ak.k0, ak.k1)
         if (f64 && ar) G2048_LAUNCH_RANDOM(true, true);
         else if (f64) G2048_LAUNCH_RANDOM(true, false);
         else if (ar) G2048_LAUNCH_RANDOM(false, true);

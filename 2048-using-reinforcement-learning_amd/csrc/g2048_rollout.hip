@@ -65,29 +65,33 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
 {
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
     __shared__ float s_obs[32];
-    {
-        const uint32_t l = threadIdx.x & 63u;
-        if (l < G2048_DIR_TABLE_WORDS) {
-            reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];
-            s_obs[l] = (float)l / 15.0f;                      // IEEE f32 quotient, once per wave
-        }
-    }
+    // At 65,536 envs a SIMD holds ONE wavefront: whatever it waits for, nothing else runs meanwhile. So everything the wavefront
+    // reads goes out at once -- the direction table's word, the lane's board / probabilities / score / mask (every lane loads:
+    // the lanes past the end a clamped, valid index whose data they drop, so that no exec region separates the loads from
+    // the table's LDS write below) and the step counter -- and the head of the wavefront is one memory round trip, not three
+    // (table word -> LDS write; counter -> keys; lane data).
+    const uint32_t l32 = threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u);
+    const uint32_t dir_word = kDirTable[l32];
+    const size_t i = (size_t)blockIdx.x * kRolloutBlock + threadIdx.x;
+    const size_t ic = i < n ? i : n - 1u;
+    const uint4 pv = boards_in[ic];
+    const float4 p = probs[ic];
+    const uint32_t sc = score[ic];
+    const uint32_t mask_loaded = mask_in ? (uint32_t)mask_in[ic] : 0u;
     // keys of this step: uniform, derived on the scalar unit from (seed, domain, step index); the index may come from a
     // device counter so that a captured hipGraph of a whole rollout can be replayed
     const uint64_t index = step_index + (step_counter ? (uint64_t)*step_counter : 0ull);
+    reinterpret_cast<uint32_t *>(s_dir)[l32] = dir_word;      // both halves of the wave write the same 32 words: no branch
+    s_obs[l32] = (float)l32 / 15.0f;                          // IEEE f32 quotient, once per wave
     const Keys kp = rng_keys(seed, DOM_POLICY, index), ks = rng_keys(seed, DOM_STEP, index), ke = rng_keys(seed, DOM_EPISODE, index);
-    const size_t i = (size_t)blockIdx.x * kRolloutBlock + threadIdx.x;
-    if (i >= n) return;
     const uint64_t id = id_base + i;
-    const uint4 pv = boards_in[i];
     const Board prev = {{pv.x, pv.y, pv.z, pv.w}};
-    const float4 p = probs[i];
-    const uint32_t sc = score[i];
-    const uint32_t mask = mask_in ? (uint32_t)mask_in[i] : valid_mask_env(prev);
+    const uint32_t mask = mask_in ? mask_loaded : valid_mask_env(prev);
     float pa;
     const uint32_t a = sample_action(p.x, p.y, p.z, p.w, mask, rng_draw(kp.k0, kp.k1, id, 0u), pa);
     const uint4 si = s_dir[2u * a], so = s_dir[2u * a + 1u];
     const StepOut o = step_board_sel(prev, DirSel{si.x, si.y, si.z, si.w, so.x, so.y, so.z, so.w}, rng_draw(ks.k0, ks.k1, id, 0u));
+    if (i >= n) return;                                      // (the lanes past the end computed on their clamped loads; they store nothing)
     if (next_boards_out) next_boards_out[i] = make_uint4(o.board.w[0], o.board.w[1], o.board.w[2], o.board.w[3]);
     if (state_max_out) state_max_out[i] = (uint8_t)max_code(prev);
     Board cur = o.board;

@@ -30,6 +30,9 @@ _FORCE = os.environ.get("G2048_DIST_FORCE") == "1"
 _DATA = None            # the RCCL group of the data plane (None: device tensors are staged through the host over gloo)
 _DATA_NOTE = None       # why the data plane is not RCCL, if it was asked for
 _PROBE_TIMEOUT_S = float(os.environ.get("G2048_RCCL_PROBE_TIMEOUT_S", "90"))
+# every wait on the control plane is bounded too (torch's default is 30 minutes): a rank that never arrives costs the others
+# five minutes and an exception, not the job's time limit
+_CONTROL_TIMEOUT_S = float(os.environ.get("G2048_CONTROL_TIMEOUT_S", "300"))
 
 
 def world():
@@ -76,7 +79,7 @@ def init(backend=None, device=None):
             # a collective that cannot complete raises in the caller after its timeout (-> the fallback above) instead of
             # the watchdog thread aborting the process
             os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=_CONTROL_TIMEOUT_S))
             _open_data_plane(device)
         else:
             dist.init_process_group(backend)
@@ -189,6 +192,8 @@ def shutdown():
     """Leave together and drop the groups (a failed RCCL probe leaves nothing to tear down on the data plane)."""
     global _DATA
     if dist.is_initialized():
-        dist.barrier()
-        _DATA = None
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+        finally:
+            _DATA = None
+            dist.destroy_process_group()

@@ -331,15 +331,18 @@ def main():
         if rank == 0:
             # the gathered vector must equal what ONE GPU computes for the same global ids: rank 0 re-runs the K timed
             # steps of every other shard (same seed, step indices and id_base = shard start) and compares
+            # (into buffers of its own: this rank's out / reward / flags still have to pass the chains check below)
             vb, va = torch.empty_like(boards), torch.empty_like(actions)
             vo, vs = torch.empty_like(boards), torch.empty_like(scores)
+            vr, vf = torch.empty_like(reward), torch.empty_like(flags)
             for r in range(1, world):
                 ops.synth_boards(n, seed=SEED, id_base=r * n, device=dev, out=vb)
                 ops.synth_actions(n, seed=SEED, step_index=0, id_base=r * n, device=dev, out=va)
                 vs.zero_()
                 for t in range(K):
-                    ops.step(vb, va, vs, SEED, W + t, r * n, out=vo, reward=reward, flags=flags)
+                    ops.step(vb, va, vs, SEED, W + t, r * n, out=vo, reward=vr, flags=vf)
                 assert bool((gathered[r * n:(r + 1) * n] == vs).all()), "shard %d differs from the 1-GPU result" % r
+            del vb, va, vo, vs, vr, vf
 
     # ---- the chain form must BE the single launch: the same K steps, one launch each, into buffers of their own
     chains_equal = None
@@ -505,449 +508,464 @@ def main():
             if ref1.get("value"):
                 result["single_gpu_reference"]["this_run_per_gpu_over_it"] = result["per_gpu_value"] / ref1["value"]
 
-    # ---- extra step legs: f64-reward parity mode at configs[1]; a working set beyond the Infinity Cache -----------
-    if not args.no_extra:
-        reward64 = torch.empty(n, dtype=torch.float64, device=dev)
+    # ---- the other legs. With one rank a failure in any of them fails the run, as it should. With several ranks the headline
+    # figures above are what the scaling curve needs: a leg that raises (or a collective in it that times out: g2048/dist.py
+    # bounds every wait) is recorded in the line as optional_legs_error and the line is still printed.
+    def _optional_legs():
+        # ---- extra step legs: f64-reward parity mode at configs[1]; a working set beyond the Infinity Cache -----------
+        if not args.no_extra:
+            reward64 = torch.empty(n, dtype=torch.float64, device=dev)
 
-        def k_steps_f64():
-            for t in range(K):
-                ops.step(boards, actions, scores, SEED, W + t, id_base, out=out, reward=reward64, flags=flags, reward_f64=True)
-        k_steps_f64()
-        g64, a64, b64 = (None, None, None) if args.no_graph else graph_of(k_steps_f64, dev)
-        ms = timed_replay(g64, a64, b64, k_steps_f64, reps=3)
-        us = ms * 1e3 / K
-        result["roofline_f64_reward"] = {"bound": "hbm", "achieved": n * STEP_BYTES_F64 / us / 1e3, "peak": HBM_PEAK_GBS,
-                                         "unit": "GB/s", "frac": n * STEP_BYTES_F64 / us / 1e3 / HBM_PEAK_GBS, "kernel_us": us,
-                                         "kernel": "step_kernel<true,false,1,256>", "bytes_per_board": STEP_BYTES_F64,
-                                         "board_steps_per_s": n / us * 1e6,
-                                         "traffic": (pmc_extra.get("f64_reward_mode") or {}).get("hbm_bytes_per_launch"),
-                                         "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
-                                                           % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
-                                         "note": "bit-exact parity mode: reward written as f64 (50 B per board-step)"}
-        del reward64, g64
-        nb = BIG_BOARDS
-        bb = ops.synth_boards(nb, seed=SEED + 7, id_base=id_base, device=dev)
-        ba = ops.synth_actions(nb, seed=SEED + 7, step_index=0, id_base=id_base, device=dev)
-        bo = torch.empty_like(bb)
-        bs = torch.zeros(nb, dtype=torch.int32, device=dev)
-        br = torch.empty(nb, dtype=torch.float32, device=dev)
-        bf = torch.empty(nb, dtype=torch.uint8, device=dev)
-        KB = 40          # 40 launches per replay (6.5 ms): long enough for steady-state clocks, the replay's fixed cost amortised
+            def k_steps_f64():
+                for t in range(K):
+                    ops.step(boards, actions, scores, SEED, W + t, id_base, out=out, reward=reward64, flags=flags, reward_f64=True)
+            k_steps_f64()
+            g64, a64, b64 = (None, None, None) if args.no_graph else graph_of(k_steps_f64, dev)
+            ms = timed_replay(g64, a64, b64, k_steps_f64, reps=3)
+            us = ms * 1e3 / K
+            result["roofline_f64_reward"] = {"bound": "hbm", "achieved": n * STEP_BYTES_F64 / us / 1e3, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": n * STEP_BYTES_F64 / us / 1e3 / HBM_PEAK_GBS, "kernel_us": us,
+                                             "kernel": "step_kernel<true,false,1,256>", "bytes_per_board": STEP_BYTES_F64,
+                                             "board_steps_per_s": n / us * 1e6,
+                                             "traffic": (pmc_extra.get("f64_reward_mode") or {}).get("hbm_bytes_per_launch"),
+                                             "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
+                                                               % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
+                                             "note": "bit-exact parity mode: reward written as f64 (50 B per board-step)"}
+            del reward64, g64
+            nb = BIG_BOARDS
+            bb = ops.synth_boards(nb, seed=SEED + 7, id_base=id_base, device=dev)
+            ba = ops.synth_actions(nb, seed=SEED + 7, step_index=0, id_base=id_base, device=dev)
+            bo = torch.empty_like(bb)
+            bs = torch.zeros(nb, dtype=torch.int32, device=dev)
+            br = torch.empty(nb, dtype=torch.float32, device=dev)
+            bf = torch.empty(nb, dtype=torch.uint8, device=dev)
+            KB = 40          # 40 launches per replay (6.5 ms): long enough for steady-state clocks, the replay's fixed cost amortised
 
-        def big_steps():
-            for t in range(KB):
-                ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
-        big_steps()
-        gb, ab, bb2 = (None, None, None) if args.no_graph else graph_of(big_steps, dev)
-        for _ in range(3):                  # untimed: fresh 738 MB of buffers (first touches, TLB), clocks to steady state
-            if gb is not None:
-                gb.replay()
-            else:
-                big_steps()
-        torch.cuda.synchronize()
-        all_ms = [timed_replay(gb, ab, bb2, big_steps, reps=1) for _ in range(4)]
-        us = min(all_ms) * 1e3 / KB
-        us_mean = sum(all_ms) / len(all_ms) * 1e3 / KB
-        result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
-                                           "frac_mean_of_4": nb * STEP_BYTES_F32 / us_mean / 1e3 / HBM_PEAK_GBS,
-                                           "kernel_us": us, "kernel_us_mean_of_4": us_mean, "boards_per_launch": nb,
-                                           "traffic": (pmc_extra.get("hbm_resident_leg") or {}).get("hbm_bytes_per_launch"),
-                                           "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
-                                                             % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
-                                           "kernel": "step_kernel<false,false,2,256> (two boards per lane from 4 Mi boards per launch on)",
-                                           "algorithmic_bytes_per_launch": nb * STEP_BYTES_F32,
-                                           "board_steps_per_s": nb / us * 1e6,
-                                           "note": "16,777,216 boards per launch: 738 MB of streams, beyond the 256 MiB "
-                                                   "Infinity Cache, so reads come from and writes go to HBM3E"}
-        # rounds 1-2 timed 10 launches per replay (1.6 ms): kept beside the 40-launch reading for like-for-like comparison
-        def big_steps10():
-            for t in range(10):
-                ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
-        g10, a10, b10 = (None, None, None) if args.no_graph else graph_of(big_steps10, dev)
-        ms10 = [timed_replay(g10, a10, b10, big_steps10, reps=1) for _ in range(4)]
-        result["roofline_hbm_resident"]["frac_10_launch_replays"] = nb * STEP_BYTES_F32 / (min(ms10) * 1e3 / 10) / 1e3 / HBM_PEAK_GBS
-        result["roofline_hbm_resident"]["frac_10_launch_replays_mean_of_4"] = (nb * STEP_BYTES_F32 / (sum(ms10) / len(ms10) * 1e3 / 10) / 1e3
-                                                                              / HBM_PEAK_GBS)
-        result["roofline_hbm_resident"]["timing"] = ("event pair around one hipGraph replay of 40 launches queued behind another one "
-                                                     "(6 ms: steady-state clocks), best and mean of four; rounds 1-2 replayed 10 launches "
-                                                     "(frac_10_launch_replays: 0.586 in round 2)")
-        del bb, ba, bo, bs, br, bf, gb, g10
-        torch.cuda.empty_cache()
+            def big_steps():
+                for t in range(KB):
+                    ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
+            big_steps()
+            gb, ab, bb2 = (None, None, None) if args.no_graph else graph_of(big_steps, dev)
+            for _ in range(3):                  # untimed: fresh 738 MB of buffers (first touches, TLB), clocks to steady state
+                if gb is not None:
+                    gb.replay()
+                else:
+                    big_steps()
+            torch.cuda.synchronize()
+            all_ms = [timed_replay(gb, ab, bb2, big_steps, reps=1) for _ in range(4)]
+            us = min(all_ms) * 1e3 / KB
+            us_mean = sum(all_ms) / len(all_ms) * 1e3 / KB
+            result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": nb * STEP_BYTES_F32 / us / 1e3, "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": nb * STEP_BYTES_F32 / us / 1e3 / HBM_PEAK_GBS,
+                                               "frac_mean_of_4": nb * STEP_BYTES_F32 / us_mean / 1e3 / HBM_PEAK_GBS,
+                                               "kernel_us": us, "kernel_us_mean_of_4": us_mean, "boards_per_launch": nb,
+                                               "traffic": (pmc_extra.get("hbm_resident_leg") or {}).get("hbm_bytes_per_launch"),
+                                               "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run"
+                                                                 % pmc_extra.get("extra_legs_source", "profiles/pmc_step.json"),
+                                               "kernel": "step_kernel<false,false,2,256> (two boards per lane from 4 Mi boards per launch on)",
+                                               "algorithmic_bytes_per_launch": nb * STEP_BYTES_F32,
+                                               "board_steps_per_s": nb / us * 1e6,
+                                               "note": "16,777,216 boards per launch: 738 MB of streams, beyond the 256 MiB "
+                                                       "Infinity Cache, so reads come from and writes go to HBM3E"}
+            # rounds 1-2 timed 10 launches per replay (1.6 ms): kept beside the 40-launch reading for like-for-like comparison
+            def big_steps10():
+                for t in range(10):
+                    ops.step(bb, ba, bs, SEED, t, id_base, out=bo, reward=br, flags=bf)
+            g10, a10, b10 = (None, None, None) if args.no_graph else graph_of(big_steps10, dev)
+            ms10 = [timed_replay(g10, a10, b10, big_steps10, reps=1) for _ in range(4)]
+            result["roofline_hbm_resident"]["frac_10_launch_replays"] = nb * STEP_BYTES_F32 / (min(ms10) * 1e3 / 10) / 1e3 / HBM_PEAK_GBS
+            result["roofline_hbm_resident"]["frac_10_launch_replays_mean_of_4"] = (nb * STEP_BYTES_F32 / (sum(ms10) / len(ms10) * 1e3 / 10) / 1e3
+                                                                                  / HBM_PEAK_GBS)
+            result["roofline_hbm_resident"]["timing"] = ("event pair around one hipGraph replay of 40 launches queued behind another one "
+                                                         "(6 ms: steady-state clocks), best and mean of four; rounds 1-2 replayed 10 launches "
+                                                         "(frac_10_launch_replays: 0.586 in round 2)")
+            del bb, ba, bo, bs, br, bf, gb, g10
+            torch.cuda.empty_cache()
 
-    # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
-    if not args.no_beam:
-        roots = beam_roots(ops, BEAM_GAMES, rank * BEAM_GAMES, dev)
-        for w in range(2):
-            a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=w,
-                                          game_id_base=rank * BEAM_GAMES, want_expanded=True)
-        torch.cuda.synchronize()
-        breps = 20
-        batches = []
-        for rep in range(3):                # three batches of 20 calls; `value` is the best batch, the mean is reported beside it
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            exps = []
-            b0.record()
-            for w in range(breps):          # back to back on one stream: the GPU never waits for the host
-                a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w,
+        # ---- beam search leg (config 3): 4096 concurrent games, width 20, depth 30 -----------
+        if not args.no_beam:
+            roots = beam_roots(ops, BEAM_GAMES, rank * BEAM_GAMES, dev)
+            for w in range(2):
+                a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=w,
                                               game_id_base=rank * BEAM_GAMES, want_expanded=True)
-                exps.append(e)
-            b1.record()
             torch.cuda.synchronize()
-            batches.append((b0.elapsed_time(b1) * 1e-3, int(torch.stack(exps).sum().item())))
-        # a fourth, separate batch with an event between every two calls: the per-call durations (kernel + one launch boundary), whose
-        # median is what a rocprofv3 kernel trace of this command shows for beam_kernel<2> (profiles/r04_bench_kernel_trace_stats.txt)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(breps + 1)]
-        marks[0].record()
-        for w in range(breps):
-            ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w, game_id_base=rank * BEAM_GAMES, want_expanded=True)
-            marks[w + 1].record()
-        torch.cuda.synchronize()
-        per_call_us = sorted(marks[w].elapsed_time(marks[w + 1]) * 1e3 for w in range(breps))
-        bsec, total_exp = min(batches)
-        beam_mean = sum(x / t for t, x in batches) / len(batches)
-        beam_best = total_exp / bsec
-        bsec_mean = sum(t for t, _ in batches) / len(batches)
-        # N > 1: every rank searched its own 4096 roots (games shard like boards); the job's figure is all ranks' expansions over
-        # the slowest rank's mean batch time
-        job_exp = world * total_exp if world == 1 else int(gdist.reduce_metrics(torch.tensor([total_exp], dtype=torch.int64, device=dev))[0].item())
-        job_sec = gdist.max_over_ranks(bsec_mean, dev)
-        result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games per GPU)",
-                          "value": beam_mean if world == 1 else job_exp / job_sec, "unit": "expansions/s",
-                          "value_best_of_3_batches": beam_best, "n_gpus": world,
-                          "timing": "HIP event pair around 20 calls queued back to back (one beam kernel each; the blocks take the games in the "
-                                    "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); `value` = mean of three "
-                                    "such batches (round 3 reported the best of three: 6.94e10 best / 6.80e10 mean then; rounds 1-2 one batch)",
-                          "decisions_per_s": BEAM_GAMES * breps / bsec_mean, "ms_per_batch_decision": bsec_mean / breps * 1e3,
-                          "parents_expanded_per_s_approx": beam_mean / 4.0,     # "parents-expanded/s (= expansions / ~4)"
-                          "ms_per_batch_decision_best": bsec / breps * 1e3,
-                          "us_per_call_median_of_20_event_pairs": per_call_us[len(per_call_us) // 2], "us_per_call_min": per_call_us[0],
-                          "gbs_equivalent_29B": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9,
-                          "gbs_equivalent_29B_frac_of_hbm_peak": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
-                          "gbs_equivalent_note": "SURVEY 8(d): 29 B per expansion if the beam lived in HBM; the search keeps it in LDS "
-                                                 "(16 B in, 5 B out per decision), so this is a comparability figure, not traffic",
-                          "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
-                          "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
-                                    "a bitonic network over the lanes; issue priority by remaining levels while the whole launch is resident; "
-                                    "games dealt to the SIMDs by depth class from the lists the previous call's blocks filed them in "
-                                    "-- no order kernel)"}
-        # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
-        # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
-        # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
-        pb = os.path.join(REPO, "profiles", "pmc_beam.json")
-        if os.path.exists(pb):
-            pj = json.load(open(pb))
-            insts = float(pj["valu_wave_instructions_per_launch"])
-            cyc = float(pj["issue_cycles_per_instruction"])
-            props = torch.cuda.get_device_properties(dev)
-            n_simd = props.multi_processor_count * SIMDS_PER_CU      # 256 CUs x 4 on MI355X; taken from the device
-            clock_ghz = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
-            peak = n_simd * clock_ghz / cyc             # G wave-instructions / s
-            ach = insts / bsec_mean * breps / 1e9            # (priced on the mean batch, like `value`)
-            result["beam"]["roofline"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
-                                          "frac": ach / peak, "valu_wave_instructions_per_launch": insts,
-                                          "issue_cycles_per_instruction": cyc, "simds": n_simd, "clock_ghz": clock_ghz,
-                                          "source": "instruction count from a recorded rocprofv3 SQ_INSTS_VALU pass (%s); "
-                                                    "time measured in this run" % pj.get("source", "profiles/pmc_beam.json")}
-
-        # BASELINE's metric has two halves; the driver's record keeps `roofline` and `cpu_baseline` whole, so a compact copy of the
-        # beam half lives there too (nested, and as flat scalars in case nested objects are dropped)
-        br = result["beam"].get("roofline", {})
-        compact = {"value": result["beam"]["value"], "unit": "expansions/s", "value_best_of_3_batches": beam_best,
-                   "ms_per_batch_decision": bsec_mean / breps * 1e3, "kernel": "beam_kernel<2>",
-                   "valu_issue_frac": br.get("frac"), "gbs_equivalent_29B_frac": result["beam"]["gbs_equivalent_29B_frac_of_hbm_peak"],
-                   "expansions_per_decision": total_exp / (BEAM_GAMES * breps), "games": BEAM_GAMES, "width": BEAM_WIDTH, "depth": BEAM_DEPTH}
-        result["roofline"]["beam"] = compact
-        for k in ("value", "ms_per_batch_decision", "valu_issue_frac", "gbs_equivalent_29B_frac", "expansions_per_decision"):
-            result["roofline"]["beam_" + k] = compact[k]
-
-    # ---- evaluation leg: 4096 beam-search games (w=20, d=30) played to completion, fused per game
-    if not args.no_evaluation and not args.no_beam and world == 1:
-        from g2048 import evaluate_beam_search
-        evaluate_beam_search(256, BEAM_WIDTH, BEAM_DEPTH, seed=1, max_moves=50, device=dev)      # warm
-        def play(games, **kw):
-            return evaluate_beam_search(games, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev, **kw)
-        runs = [(play(BEAM_GAMES, one_phase=True), play(BEAM_GAMES), play(100)) for _ in range(2)]     # interleaved, best of two
-        ev1, ev, ev100 = (min((r[k] for r in runs), key=lambda x: x["elapsed_s"]) for k in range(3))
-        sm = ev["summary"]
-        result["evaluation"] = {"metric": "4096 complete beam-search games (width 20, depth 30, 5000-move cap), one launch",
-                                "seconds": ev["elapsed_s"], "seconds_without_helper_wavefronts": ev1["elapsed_s"],
-                                "same_games_without_helpers": ev["scores"] == ev1["scores"] and ev["moves"] == ev1["moves"],
-                                "seconds_100_games": ev100["elapsed_s"],
-                                "moves": ev["total_moves"], "moves_per_s": sm["moves_per_s"],
-                                "expansions_per_s": sm["expansions_per_s"], "rate_2048_or_more": sm["rate_2048_or_more"],
-                                "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
-                                                                                                "average_score": 18945.6}}
-        torch.cuda.synchronize()
-        h0 = time.perf_counter()
-        evh = play(BEAM_GAMES, histories="best5")           # the same evaluation with the action stream recorded + five games replayed
-        torch.cuda.synchronize()
-        # evaluate_beam_search stops its own clock before the replay of the asked games: `elapsed_s` holds the action stream only,
-        # the whole call (replay launch, unpack, the host-side history lists) is timed here
-        result["evaluation"]["seconds_with_action_stream"] = evh["elapsed_s"]
-        result["evaluation"]["seconds_with_action_stream_and_best5_histories"] = time.perf_counter() - h0
-        result["evaluation"]["same_games_with_action_stream"] = evh["scores"] == ev["scores"] and evh["moves"] == ev["moves"]
-        ec = {"seconds": ev["elapsed_s"], "moves": ev["total_moves"], "same_games_without_helpers": result["evaluation"]["same_games_without_helpers"],
-              "seconds_without_helper_wavefronts": ev1["elapsed_s"], "expansions_per_s": sm["expansions_per_s"], "games": BEAM_GAMES}
-        result["roofline"]["evaluation"] = ec
-        for k in ("seconds", "moves", "same_games_without_helpers"):
-            result["roofline"]["evaluation_" + k] = ec[k]
-
-    # ---- sharded evaluation (N > 1): every rank plays 512 games of one evaluation, one all-gather of the per-game table.
-    # A failure here must not cost the headline line: it is reported, not raised.
-    if not args.no_evaluation and not args.no_beam and world > 1:
-        try:
-            from g2048 import evaluate_beam_search_sharded
-            evs = evaluate_beam_search_sharded(512 * world, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
-            result["evaluation_sharded"] = {"metric": "one beam-search evaluation (width 20, depth 30, 5000-move cap) of 512 games "
-                                                      "per rank, games sharded by contiguous id range, one all-gather at the end",
-                                            "games": len(evs["scores"]), "n_ranks": evs["parameters"]["world_size"],
-                                            "seconds_slowest_rank": evs["elapsed_s"], "moves": evs["total_moves"],
-                                            "rate_2048_or_more": evs["summary"]["rate_2048_or_more"],
-                                            "average_score": evs["summary"]["average_score"]}
-        except Exception as exc:                # noqa: BLE001
-            result["evaluation_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
-    # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions,
-    # auto-reset on (realistic tile distribution instead of the synthetic one). g2048_step_many runs all 128 steps of a board
-    # in ONE launch with the board in registers (per-step f32 rewards streamed out, final boards / scores / flags); the
-    # 128-launch form (one hipGraph of g2048_step launches, each re-reading and re-writing 46 B per board) is timed beside it.
-    if not args.no_rollout:
-        T_ROLL = 128
-        rb, rs = ops.reset(n, SEED, 0, id_base, device=dev)
-        rstream = torch.empty((T_ROLL, n), dtype=torch.float32, device=dev)
-
-        def many(t0, stream):
-            ops.step_many(rb, rs, SEED, t0, T_ROLL, id_base, out=rb, flags=flags, auto_reset=True, reward_stream=stream)
-
-        def time_many(stream):
-            best = None
-            for rep in range(5):
-                m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                m0.record()
-                many(T_ROLL * (3 + rep), stream)
-                m1.record()
+            breps = 20
+            batches = []
+            for rep in range(3):                # three batches of 20 calls; `value` is the best batch, the mean is reported beside it
+                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                exps = []
+                b0.record()
+                for w in range(breps):          # back to back on one stream: the GPU never waits for the host
+                    a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w,
+                                                  game_id_base=rank * BEAM_GAMES, want_expanded=True)
+                    exps.append(e)
+                b1.record()
                 torch.cuda.synchronize()
-                ms = m0.elapsed_time(m1)
-                best = ms if best is None else min(best, ms)
-            return best
-        for w in range(3):                      # untimed: first-touch of the 512 MB reward stream, clocks to steady state
-            many(w * T_ROLL, rstream)
-        torch.cuda.synchronize()
-        ms_stream, ms_bare = time_many(rstream), time_many(None)
-
-        def rollout_steps(t0=128):
-            for t in range(t0, t0 + 128):
-                ops.step(rb, None, rs, SEED, t, id_base, out=rb, reward=reward, flags=flags, auto_reset=True)
-        rollout_steps(0)
-        torch.cuda.synchronize()
-        rg, ra, rbv = (None, None, None) if args.no_graph else graph_of(rollout_steps, dev)
-        ms = timed_replay(rg, ra, rbv, rollout_steps, reps=2)
-        result["rollout_random"] = {"metric": "board-steps/s, 1,048,576 boards x 128 consecutive in-place steps from reset, "
-                                              "uniform actions drawn in the kernel, auto-reset (realistic tile distribution); "
-                                              "ONE g2048_step_many launch, boards in registers, per-step f32 rewards streamed out",
-                                    "value": n * T_ROLL / (ms_stream * 1e-3), "unit": "board-steps/s",
-                                    "us_per_step": ms_stream * 1e3 / T_ROLL,
-                                    "kernel": "step_many_kernel<false,true,256>",
-                                    "without_reward_stream": {"value": n * T_ROLL / (ms_bare * 1e-3), "us_per_step": ms_bare * 1e3 / T_ROLL,
-                                                              "note": "no per-step output requested: the shaped reward is not computed"},
-                                    "as_128_step_launches": {"value": n * 128 / (ms * 1e-3), "us_per_step": ms * 1e3 / 128,
-                                                             "note": "round 2's form: one hipGraph of 128 g2048_step launches"}}
-        del rstream
-
-    # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
-    if not args.no_rollout and not args.no_ppo_rollout and world == 1:
-        import torch.nn as nn
-        from g2048 import RolloutCollector
-
-        class Policy(nn.Module):            # the reference's models/transformer.py shape, stock torch, random init
-            def __init__(self):
-                super().__init__()
-                self.emb = nn.Linear(1, 64)
-                self.enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(64, 4, 128, batch_first=True), 2)
-                self.fc = nn.Sequential(nn.Linear(1024, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU())
-                self.actor, self.critic = nn.Linear(64, 4), nn.Linear(64, 1)
-
-            def forward(self, x):
-                h = self.fc(self.enc(self.emb(x.view(x.shape[0], 16, 1))).reshape(x.shape[0], -1))
-                return torch.softmax(self.actor(h), -1), self.critic(h)
-
-        class ActorCritic(nn.Module):       # the MLP shapes agents/ppo_agent.py:61-136 actually uses (16-256-128-64-4 / -1,
-            def __init__(self):             # BatchNorm + ReLU, eval mode), stock torch, random init
-                super().__init__()
-                def trunk():
-                    return nn.Sequential(nn.Linear(16, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 128), nn.BatchNorm1d(128),
-                                         nn.ReLU(), nn.Linear(128, 64), nn.BatchNorm1d(64), nn.ReLU())
-                self.actor, self.critic = nn.Sequential(trunk(), nn.Linear(64, 4)), nn.Sequential(trunk(), nn.Linear(64, 1))
-
-            def forward(self, x):
-                return torch.softmax(self.actor(x), -1), self.critic(x)
-
-        class Uniform(nn.Module):           # no network: isolates the env side of the rollout
-            def forward(self, x):
-                return torch.full((x.shape[0], 4), 0.25, device=x.device)
-
-        torch.manual_seed(0)
-        rres = {}
-        for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("mlp_actor_critic_policy", ActorCritic().to(dev).eval()),
-                          ("uniform_policy_env_only", Uniform())):
-            rc = RolloutCollector(65536, 128, pol, device=dev, seed=SEED)
-            rc.collect()                    # includes the one-time graph capture
-            rc.collect()
+                batches.append((b0.elapsed_time(b1) * 1e-3, int(torch.stack(exps).sum().item())))
+            # a fourth, separate batch with an event between every two calls: the per-call durations (kernel + one launch boundary), whose
+            # median is what a rocprofv3 kernel trace of this command shows for beam_kernel<2> (profiles/r04_bench_kernel_trace_stats.txt)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(breps + 1)]
+            marks[0].record()
+            for w in range(breps):
+                ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + w, game_id_base=rank * BEAM_GAMES, want_expanded=True)
+                marks[w + 1].record()
             torch.cuda.synchronize()
-            best = None
-            for _ in range(3 if name != "transformer_policy" else 1):
-                r0 = time.perf_counter()
+            per_call_us = sorted(marks[w].elapsed_time(marks[w + 1]) * 1e3 for w in range(breps))
+            bsec, total_exp = min(batches)
+            beam_mean = sum(x / t for t, x in batches) / len(batches)
+            beam_best = total_exp / bsec
+            bsec_mean = sum(t for t, _ in batches) / len(batches)
+            # N > 1: every rank searched its own 4096 roots (games shard like boards); the job's figure is all ranks' expansions over
+            # the slowest rank's mean batch time
+            job_exp = world * total_exp if world == 1 else int(gdist.reduce_metrics(torch.tensor([total_exp], dtype=torch.int64, device=dev))[0].item())
+            job_sec = gdist.max_over_ranks(bsec_mean, dev)
+            result["beam"] = {"metric": "beam node-expansions/s (width=20, depth=30, 4096 concurrent games per GPU)",
+                              "value": beam_mean if world == 1 else job_exp / job_sec, "unit": "expansions/s",
+                              "value_best_of_3_batches": beam_best, "n_gpus": world,
+                              "timing": "HIP event pair around 20 calls queued back to back (one beam kernel each; the blocks take the games in the "
+                                        "depth-balanced order the previous call left behind, g2048_beam_get_action_hist); `value` = mean of three "
+                                        "such batches (round 3 reported the best of three: 6.94e10 best / 6.80e10 mean then; rounds 1-2 one batch)",
+                              "decisions_per_s": BEAM_GAMES * breps / bsec_mean, "ms_per_batch_decision": bsec_mean / breps * 1e3,
+                              "parents_expanded_per_s_approx": beam_mean / 4.0,     # "parents-expanded/s (= expansions / ~4)"
+                              "ms_per_batch_decision_best": bsec / breps * 1e3,
+                              "us_per_call_median_of_20_event_pairs": per_call_us[len(per_call_us) // 2], "us_per_call_min": per_call_us[0],
+                              "gbs_equivalent_29B": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9,
+                              "gbs_equivalent_29B_frac_of_hbm_peak": beam_mean * BEAM_BYTES_PER_EXPANSION / 1e9 / HBM_PEAK_GBS,
+                              "gbs_equivalent_note": "SURVEY 8(d): 29 B per expansion if the beam lived in HBM; the search keeps it in LDS "
+                                                     "(16 B in, 5 B out per decision), so this is a comparability figure, not traffic",
+                              "expansions_per_decision": total_exp / (BEAM_GAMES * breps),
+                              "kernel": "beam_kernel<2> (one wavefront per game; spawn + score in up to two 64-child passes per level, ranking by "
+                                        "a bitonic network over the lanes; issue priority by remaining levels while the whole launch is resident; "
+                                        "games dealt to the SIMDs by depth class from the lists the previous call's blocks filed them in "
+                                        "-- no order kernel)"}
+            # the beam lives in LDS (HBM traffic per decision: 16 B in, 5 B out), so its bound is VALU issue, not memory:
+            # wave-instructions per launch (SQ_INSTS_VALU, recorded rocprofv3 pass) / measured launch time, against what the
+            # chip's 1024 SIMDs can issue at the kernel's average cost per instruction (tools/isa_cost.py)
+            pb = os.path.join(REPO, "profiles", "pmc_beam.json")
+            if os.path.exists(pb):
+                pj = json.load(open(pb))
+                insts = float(pj["valu_wave_instructions_per_launch"])
+                cyc = float(pj["issue_cycles_per_instruction"])
+                props = torch.cuda.get_device_properties(dev)
+                n_simd = props.multi_processor_count * SIMDS_PER_CU      # 256 CUs x 4 on MI355X; taken from the device
+                clock_ghz = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
+                peak = n_simd * clock_ghz / cyc             # G wave-instructions / s
+                ach = insts / bsec_mean * breps / 1e9            # (priced on the mean batch, like `value`)
+                result["beam"]["roofline"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+                                              "frac": ach / peak, "valu_wave_instructions_per_launch": insts,
+                                              "issue_cycles_per_instruction": cyc, "simds": n_simd, "clock_ghz": clock_ghz,
+                                              "source": "instruction count from a recorded rocprofv3 SQ_INSTS_VALU pass (%s); "
+                                                        "time measured in this run" % pj.get("source", "profiles/pmc_beam.json")}
+
+            # BASELINE's metric has two halves; the driver's record keeps `roofline` and `cpu_baseline` whole, so a compact copy of the
+            # beam half lives there too (nested, and as flat scalars in case nested objects are dropped)
+            br = result["beam"].get("roofline", {})
+            compact = {"value": result["beam"]["value"], "unit": "expansions/s", "value_best_of_3_batches": beam_best,
+                       "ms_per_batch_decision": bsec_mean / breps * 1e3, "kernel": "beam_kernel<2>",
+                       "valu_issue_frac": br.get("frac"), "gbs_equivalent_29B_frac": result["beam"]["gbs_equivalent_29B_frac_of_hbm_peak"],
+                       "expansions_per_decision": total_exp / (BEAM_GAMES * breps), "games": BEAM_GAMES, "width": BEAM_WIDTH, "depth": BEAM_DEPTH}
+            result["roofline"]["beam"] = compact
+            for k in ("value", "ms_per_batch_decision", "valu_issue_frac", "gbs_equivalent_29B_frac", "expansions_per_decision"):
+                result["roofline"]["beam_" + k] = compact[k]
+
+        # ---- evaluation leg: 4096 beam-search games (w=20, d=30) played to completion, fused per game
+        if not args.no_evaluation and not args.no_beam and world == 1:
+            from g2048 import evaluate_beam_search
+            evaluate_beam_search(256, BEAM_WIDTH, BEAM_DEPTH, seed=1, max_moves=50, device=dev)      # warm
+            def play(games, **kw):
+                return evaluate_beam_search(games, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev, **kw)
+            runs = [(play(BEAM_GAMES, one_phase=True), play(BEAM_GAMES), play(100)) for _ in range(2)]     # interleaved, best of two
+            ev1, ev, ev100 = (min((r[k] for r in runs), key=lambda x: x["elapsed_s"]) for k in range(3))
+            sm = ev["summary"]
+            result["evaluation"] = {"metric": "4096 complete beam-search games (width 20, depth 30, 5000-move cap), one launch",
+                                    "seconds": ev["elapsed_s"], "seconds_without_helper_wavefronts": ev1["elapsed_s"],
+                                    "same_games_without_helpers": ev["scores"] == ev1["scores"] and ev["moves"] == ev1["moves"],
+                                    "seconds_100_games": ev100["elapsed_s"],
+                                    "moves": ev["total_moves"], "moves_per_s": sm["moves_per_s"],
+                                    "expansions_per_s": sm["expansions_per_s"], "rate_2048_or_more": sm["rate_2048_or_more"],
+                                    "average_score": sm["average_score"], "reference_report_md": {"rate_2048_or_more": 0.35,
+                                                                                                    "average_score": 18945.6}}
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            evh = play(BEAM_GAMES, histories="best5")           # the same evaluation with the action stream recorded + five games replayed
+            torch.cuda.synchronize()
+            # evaluate_beam_search stops its own clock before the replay of the asked games: `elapsed_s` holds the action stream only,
+            # the whole call (replay launch, unpack, the host-side history lists) is timed here
+            result["evaluation"]["seconds_with_action_stream"] = evh["elapsed_s"]
+            result["evaluation"]["seconds_with_action_stream_and_best5_histories"] = time.perf_counter() - h0
+            result["evaluation"]["same_games_with_action_stream"] = evh["scores"] == ev["scores"] and evh["moves"] == ev["moves"]
+            ec = {"seconds": ev["elapsed_s"], "moves": ev["total_moves"], "same_games_without_helpers": result["evaluation"]["same_games_without_helpers"],
+                  "seconds_without_helper_wavefronts": ev1["elapsed_s"], "expansions_per_s": sm["expansions_per_s"], "games": BEAM_GAMES}
+            result["roofline"]["evaluation"] = ec
+            for k in ("seconds", "moves", "same_games_without_helpers"):
+                result["roofline"]["evaluation_" + k] = ec[k]
+
+        # ---- sharded evaluation (N > 1): every rank plays 512 games of one evaluation, one all-gather of the per-game table.
+        # A failure here must not cost the headline line: it is reported, not raised.
+        if not args.no_evaluation and not args.no_beam and world > 1:
+            try:
+                from g2048 import evaluate_beam_search_sharded
+                evs = evaluate_beam_search_sharded(512 * world, BEAM_WIDTH, BEAM_DEPTH, seed=2025, max_moves=5000, device=dev)
+                result["evaluation_sharded"] = {"metric": "one beam-search evaluation (width 20, depth 30, 5000-move cap) of 512 games "
+                                                          "per rank, games sharded by contiguous id range, one all-gather at the end",
+                                                "games": len(evs["scores"]), "n_ranks": evs["parameters"]["world_size"],
+                                                "seconds_slowest_rank": evs["elapsed_s"], "moves": evs["total_moves"],
+                                                "rate_2048_or_more": evs["summary"]["rate_2048_or_more"],
+                                                "average_score": evs["summary"]["average_score"]}
+            except Exception as exc:                # noqa: BLE001
+                result["evaluation_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+        # ---- C2 "rollout" variant: 128 consecutive in-place steps from reset states, on-device random actions,
+        # auto-reset on (realistic tile distribution instead of the synthetic one). g2048_step_many runs all 128 steps of a board
+        # in ONE launch with the board in registers (per-step f32 rewards streamed out, final boards / scores / flags); the
+        # 128-launch form (one hipGraph of g2048_step launches, each re-reading and re-writing 46 B per board) is timed beside it.
+        if not args.no_rollout:
+            T_ROLL = 128
+            rb, rs = ops.reset(n, SEED, 0, id_base, device=dev)
+            rstream = torch.empty((T_ROLL, n), dtype=torch.float32, device=dev)
+
+            def many(t0, stream):
+                ops.step_many(rb, rs, SEED, t0, T_ROLL, id_base, out=rb, flags=flags, auto_reset=True, reward_stream=stream)
+
+            def time_many(stream):
+                best = None
+                for rep in range(5):
+                    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    m0.record()
+                    many(T_ROLL * (3 + rep), stream)
+                    m1.record()
+                    torch.cuda.synchronize()
+                    ms = m0.elapsed_time(m1)
+                    best = ms if best is None else min(best, ms)
+                return best
+            for w in range(3):                      # untimed: first-touch of the 512 MB reward stream, clocks to steady state
+                many(w * T_ROLL, rstream)
+            torch.cuda.synchronize()
+            ms_stream, ms_bare = time_many(rstream), time_many(None)
+
+            def rollout_steps(t0=128):
+                for t in range(t0, t0 + 128):
+                    ops.step(rb, None, rs, SEED, t, id_base, out=rb, reward=reward, flags=flags, auto_reset=True)
+            rollout_steps(0)
+            torch.cuda.synchronize()
+            rg, ra, rbv = (None, None, None) if args.no_graph else graph_of(rollout_steps, dev)
+            ms = timed_replay(rg, ra, rbv, rollout_steps, reps=2)
+            result["rollout_random"] = {"metric": "board-steps/s, 1,048,576 boards x 128 consecutive in-place steps from reset, "
+                                                  "uniform actions drawn in the kernel, auto-reset (realistic tile distribution); "
+                                                  "ONE g2048_step_many launch, boards in registers, per-step f32 rewards streamed out",
+                                        "value": n * T_ROLL / (ms_stream * 1e-3), "unit": "board-steps/s",
+                                        "us_per_step": ms_stream * 1e3 / T_ROLL,
+                                        "kernel": "step_many_kernel<false,true,256>",
+                                        "without_reward_stream": {"value": n * T_ROLL / (ms_bare * 1e-3), "us_per_step": ms_bare * 1e3 / T_ROLL,
+                                                                  "note": "no per-step output requested: the shaped reward is not computed"},
+                                        "as_128_step_launches": {"value": n * 128 / (ms * 1e-3), "us_per_step": ms * 1e3 / 128,
+                                                                 "note": "round 2's form: one hipGraph of 128 g2048_step launches"}}
+            del rstream
+
+        # ---- PPO rollout leg (config 4): 65,536 envs x 128 steps, transformer policy on PyTorch-ROCm -----
+        if not args.no_rollout and not args.no_ppo_rollout and world == 1:
+            import torch.nn as nn
+            from g2048 import RolloutCollector
+
+            class Policy(nn.Module):            # the reference's models/transformer.py shape, stock torch, random init
+                def __init__(self):
+                    super().__init__()
+                    self.emb = nn.Linear(1, 64)
+                    self.enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(64, 4, 128, batch_first=True), 2)
+                    self.fc = nn.Sequential(nn.Linear(1024, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU())
+                    self.actor, self.critic = nn.Linear(64, 4), nn.Linear(64, 1)
+
+                def forward(self, x):
+                    h = self.fc(self.enc(self.emb(x.view(x.shape[0], 16, 1))).reshape(x.shape[0], -1))
+                    return torch.softmax(self.actor(h), -1), self.critic(h)
+
+            class ActorCritic(nn.Module):       # the MLP shapes agents/ppo_agent.py:61-136 actually uses (16-256-128-64-4 / -1,
+                def __init__(self):             # BatchNorm + ReLU, eval mode), stock torch, random init
+                    super().__init__()
+                    def trunk():
+                        return nn.Sequential(nn.Linear(16, 256), nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 128), nn.BatchNorm1d(128),
+                                             nn.ReLU(), nn.Linear(128, 64), nn.BatchNorm1d(64), nn.ReLU())
+                    self.actor, self.critic = nn.Sequential(trunk(), nn.Linear(64, 4)), nn.Sequential(trunk(), nn.Linear(64, 1))
+
+                def forward(self, x):
+                    return torch.softmax(self.actor(x), -1), self.critic(x)
+
+            class Uniform(nn.Module):           # no network: isolates the env side of the rollout
+                def forward(self, x):
+                    return torch.full((x.shape[0], 4), 0.25, device=x.device)
+
+            torch.manual_seed(0)
+            rres = {}
+            for name, pol in (("transformer_policy", Policy().to(dev).eval()), ("mlp_actor_critic_policy", ActorCritic().to(dev).eval()),
+                              ("uniform_policy_env_only", Uniform())):
+                rc = RolloutCollector(65536, 128, pol, device=dev, seed=SEED)
+                rc.collect()                    # includes the one-time graph capture
                 rc.collect()
                 torch.cuda.synchronize()
-                dt = time.perf_counter() - r0
-                best = dt if best is None else min(best, dt)
-            rres[name] = 65536 * 128 / best
-            rres[name + "_graph"] = rc._graph is not None
-        # the env half of config 4 on its own: g2048_rollout_step at 65,536 envs with a fixed probability tensor, 128 launches from one
-        # hipGraph (tools/rollout_rate.py) -> the kernel's launch time for its roofline block
-        RN, RT, ROLLOUT_BYTES = 65536, 128, 132          # 132 B per env-step: R board 16 + probs 16 + mask 1 + score 4; W board 16 +
-        rbd, rsc = ops.reset(RN, SEED, 0, 0, device=dev)  # score 4 + action 1 + prob 4 + reward 4 + flags 1 + next obs 64 + next mask 1
-        rsp, rpr = torch.empty_like(rbd), torch.full((RN, 4), 0.25, device=dev)
-        robs = torch.empty((2, RN, 16), dtype=torch.float32, device=dev)
-        rmk = torch.empty((2, RN), dtype=torch.uint8, device=dev)
-        ops.valid_moves(rbd, out=rmk[0])
-        rac, rpb = torch.empty(RN, dtype=torch.uint8, device=dev), torch.empty(RN, device=dev)
-        rrw, rfl = torch.empty(RN, device=dev), torch.empty(RN, dtype=torch.uint8, device=dev)
-        rcnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                best = None
+                for _ in range(3 if name != "transformer_policy" else 1):
+                    r0 = time.perf_counter()
+                    rc.collect()
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - r0
+                    best = dt if best is None else min(best, dt)
+                rres[name] = 65536 * 128 / best
+                rres[name + "_graph"] = rc._graph is not None
+            # the env half of config 4 on its own: g2048_rollout_step at 65,536 envs with a fixed probability tensor, 128 launches from one
+            # hipGraph (tools/rollout_rate.py) -> the kernel's launch time for its roofline block
+            RN, RT, ROLLOUT_BYTES = 65536, 128, 132          # 132 B per env-step: R board 16 + probs 16 + mask 1 + score 4; W board 16 +
+            rbd, rsc = ops.reset(RN, SEED, 0, 0, device=dev)  # score 4 + action 1 + prob 4 + reward 4 + flags 1 + next obs 64 + next mask 1
+            rsp, rpr = torch.empty_like(rbd), torch.full((RN, 4), 0.25, device=dev)
+            robs = torch.empty((2, RN, 16), dtype=torch.float32, device=dev)
+            rmk = torch.empty((2, RN), dtype=torch.uint8, device=dev)
+            ops.valid_moves(rbd, out=rmk[0])
+            rac, rpb = torch.empty(RN, dtype=torch.uint8, device=dev), torch.empty(RN, device=dev)
+            rrw, rfl = torch.empty(RN, device=dev), torch.empty(RN, dtype=torch.uint8, device=dev)
+            rcnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
-        def rollout_launches():
-            b, sp_ = rbd, rsp
-            for t in range(RT):
-                ops.rollout_step(b, rpr, rsc, SEED, t, 0, mask=rmk[t & 1], out=sp_, actions=rac, prob=rpb, reward=rrw, flags=rfl,
-                                 obs_next=robs[(t + 1) & 1], mask_next=rmk[(t + 1) & 1], step_counter=rcnt)
-                b, sp_ = sp_, b
-        rollout_launches()
-        torch.cuda.synchronize()
-        rg_, ra_, rb_ = (None, None, None) if args.no_graph else graph_of(rollout_launches, dev)
-        r_us = timed_replay(rg_, ra_, rb_, rollout_launches, reps=4) * 1e3 / RT
-        pr_path = os.path.join(REPO, "profiles", "pmc_rollout.json")
-        prj = json.load(open(pr_path)) if os.path.exists(pr_path) else {}
-        props = torch.cuda.get_device_properties(dev)
-        n_simd_r = props.multi_processor_count * SIMDS_PER_CU
-        clock_r = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
-        rollout_roofline = {"bound": "latency (one wavefront per SIMD)", "achieved": RN * ROLLOUT_BYTES / r_us / 1e3, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": RN * ROLLOUT_BYTES / r_us / 1e3 / HBM_PEAK_GBS, "kernel": "rollout_step_kernel",
-                            "kernel_us": r_us, "envs_per_launch": RN, "algorithmic_bytes_per_launch": RN * ROLLOUT_BYTES,
-                            "traffic": prj.get("hbm_bytes_per_launch"), "env_steps_per_s_kernel_only": RN / r_us * 1e6,
-                            "valu_busy_frac_by_counter": (float(prj["active_inst_valu_quad_cycles_per_launch"]) * 4.0
-                                                          / (n_simd_r * clock_r * 1e9) / (r_us * 1e-6)) if prj.get("active_inst_valu_quad_cycles_per_launch") else None,
-                            "wait_frac_of_wave_cycles_by_counter": prj.get("wait_any_frac"),
-                            "timing": "event pair around one hipGraph replay of 128 launches queued behind another, best of four, / 128",
-                            "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run" % prj.get("source", "profiles/pmc_rollout.json"),
-                            "note": "65,536 envs = 1,024 wavefronts = ONE per SIMD: nothing hides a wavefront's load -> 868 VALU -> store "
-                                    "chain, so the launch is latency-bound (61 % of wave-cycles parked on s_waitcnt, 22 % VALU-active), far "
-                                    "from both the HBM and the VALU-issue limit; at 1,048,576 envs the same kernel reaches 0.58 of HBM "
-                                    "(tools/rollout_rate.py). The policy network dominates a real rollout either way."}
-        del rg_, rbd, rsp, robs
-        result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps: policy -> g2048_rollout_step (sample + step + next "
-                                       "obs + next mask in one launch, auto-reset), the T-step loop replayed from one hipGraph",
-                             "unit": "env-steps/s", **rres, "roofline": rollout_roofline,
-                             "note": "the policies are stock PyTorch-ROCm modules (the consumers of the rollout, not part of the hot "
-                                     "path): the reference's unused 16-token transformer (its time is torch's layer-norm / attention "
-                                     "kernels), the MLP actor / critic its PPO agent really uses, and no network at all"}
+            def rollout_launches():
+                b, sp_ = rbd, rsp
+                for t in range(RT):
+                    ops.rollout_step(b, rpr, rsc, SEED, t, 0, mask=rmk[t & 1], out=sp_, actions=rac, prob=rpb, reward=rrw, flags=rfl,
+                                     obs_next=robs[(t + 1) & 1], mask_next=rmk[(t + 1) & 1], step_counter=rcnt)
+                    b, sp_ = sp_, b
+            rollout_launches()
+            torch.cuda.synchronize()
+            rg_, ra_, rb_ = (None, None, None) if args.no_graph else graph_of(rollout_launches, dev)
+            r_us = timed_replay(rg_, ra_, rb_, rollout_launches, reps=4) * 1e3 / RT
+            pr_path = os.path.join(REPO, "profiles", "pmc_rollout.json")
+            prj = json.load(open(pr_path)) if os.path.exists(pr_path) else {}
+            props = torch.cuda.get_device_properties(dev)
+            n_simd_r = props.multi_processor_count * SIMDS_PER_CU
+            clock_r = (getattr(props, "clock_rate", 0) or 2400000) / 1e6
+            rollout_roofline = {"bound": "latency (one wavefront per SIMD)", "achieved": RN * ROLLOUT_BYTES / r_us / 1e3, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": RN * ROLLOUT_BYTES / r_us / 1e3 / HBM_PEAK_GBS, "kernel": "rollout_step_kernel",
+                                "kernel_us": r_us, "envs_per_launch": RN, "algorithmic_bytes_per_launch": RN * ROLLOUT_BYTES,
+                                "traffic": prj.get("hbm_bytes_per_launch"), "env_steps_per_s_kernel_only": RN / r_us * 1e6,
+                                "valu_busy_frac_by_counter": (float(prj["active_inst_valu_quad_cycles_per_launch"]) * 4.0
+                                                              / (n_simd_r * clock_r * 1e9) / (r_us * 1e-6)) if prj.get("active_inst_valu_quad_cycles_per_launch") else None,
+                                "wait_frac_of_wave_cycles_by_counter": prj.get("wait_any_frac"),
+                                "timing": "event pair around one hipGraph replay of 128 launches queued behind another, best of four, / 128",
+                                "traffic_source": "recorded rocprofv3 PMC passes (%s), not an observation of this run" % prj.get("source", "profiles/pmc_rollout.json"),
+                                "note": "65,536 envs = 1,024 wavefronts = ONE per SIMD: nothing hides a wavefront's load -> 868 VALU -> store "
+                                        "chain, so the launch is latency-bound (61 % of wave-cycles parked on s_waitcnt, 22 % VALU-active), far "
+                                        "from both the HBM and the VALU-issue limit; at 1,048,576 envs the same kernel reaches 0.58 of HBM "
+                                        "(tools/rollout_rate.py). The policy network dominates a real rollout either way."}
+            del rg_, rbd, rsp, robs
+            result["rollout"] = {"metric": "env-steps/s, 65,536 envs x 128 steps: policy -> g2048_rollout_step (sample + step + next "
+                                           "obs + next mask in one launch, auto-reset), the T-step loop replayed from one hipGraph",
+                                 "unit": "env-steps/s", **rres, "roofline": rollout_roofline,
+                                 "note": "the policies are stock PyTorch-ROCm modules (the consumers of the rollout, not part of the hot "
+                                         "path): the reference's unused 16-token transformer (its time is torch's layer-norm / attention "
+                                         "kernels), the MLP actor / critic its PPO agent really uses, and no network at all"}
 
-    # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        info = cpu_info()
-        hb, ha = boards.cpu().numpy(), actions.cpu().numpy()
-        hs = np.zeros(n, np.uint32)
-        O.step_batch(hb[:4096], ha[:4096], hs[:4096], seed=SEED, step_index=0)       # load + warm
+        # ---- cpu_baseline leg: the oracle (C port of the reference algorithm) on the host cores --
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            info = cpu_info()
+            hb, ha = boards.cpu().numpy(), actions.cpu().numpy()
+            hs = np.zeros(n, np.uint32)
+            O.step_batch(hb[:4096], ha[:4096], hs[:4096], seed=SEED, step_index=0)       # load + warm
 
-        def time_steps(threads, seconds):
-            O.set_num_threads(threads)
-            c0 = time.perf_counter(); passes = 0; last = None
-            while time.perf_counter() - c0 < seconds and passes < 1000:
-                last = O.step_batch(hb, ha, hs, seed=SEED, step_index=W + passes, id_base=id_base)
-                passes += 1
-            return passes, time.perf_counter() - c0, last
-        # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the box's CPU
-        # share (16 for one GPU) or to the cores this process may run on, whichever is smaller
-        many = min(16, info["affinity"])
-        every = min(info["affinity"], 512)      # all the host cores this process may run on ("1 core and all host cores")
-        p1, s1, _ = time_steps(1, args.cpu_seconds * 0.35)
-        pa, sa, _ = time_steps(every, args.cpu_seconds * 0.25) if every > many else (0, 1.0, None)
-        passes, csec, (bo_, so_, ro_, fo_) = time_steps(many, args.cpu_seconds * 0.4)
-        result["cpu_baseline"] = {"value": n * passes / csec, "unit": "board-steps/s", "cores": O.num_threads(),
-                                  "kind": "port",
-                                  "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
-                                            "(%.1f s, OpenMP static over boards)" % (passes, csec),
-                                  "one_thread": {"value": n * p1 / s1, "cores": 1,
-                                                 "sample": "%d passes, %.1f s" % (p1, s1)},
-                                  "all_affinity_cores": ({"value": n * pa / sa, "cores": every,
-                                                          "sample": "%d passes, %.1f s, one OpenMP thread per core in the affinity mask "
-                                                                    "(slower than `value` where the box's CPU share is smaller than the mask: "
-                                                                    "see cgroup_cpu_quota_cores)" % (pa, sa)} if every > many else None),
-                                  **info}
-        from oracle import pyref
-        prate = pyref.time_steps(4000, SEED)
-        result["cpu_baseline_python"] = {"value": prate, "unit": "board-steps/s", "cores": 1, "kind": "port",
-                                         "sample": "4000 steps of one board, reference-style per-board NumPy env "
-                                                   "(oracle/pyref.py), auto-reset",
-                                         "calibration": "the reference's own Game2048Env ran at 0.88x this env's rate on "
-                                                        "the same core in the build container (2.55e3 vs 2.92e3 steps/s)"}
-        # config 1 (the reference's own CPU-runnable case) through the drop-in class: a train.py-shaped iteration
-        # (get_valid_moves + step, train.py:55-75) = one g2048_env_step launch + one synchronisation
-        from environment.game_2048 import Game2048Env
-        denv = Game2048Env(seed=SEED)
-        for i in range(200):
-            denv.get_valid_moves(); denv.step(i & 3)
-        d0 = time.perf_counter(); dsteps = 0
-        while dsteps < 4000:
-            denv.get_valid_moves()
-            if denv.step(dsteps & 3)[2]:
-                denv.reset()
-            dsteps += 1
-        drate = dsteps / (time.perf_counter() - d0)
-        result["cpu_baseline_python"]["drop_in_steps_per_s"] = drate
-        result["cpu_baseline_python"]["drop_in_note"] = ("environment.game_2048.Game2048Env on the GPU, one board, get_valid_moves() + step() "
-                                                         "per iteration: one g2048_env_step launch + one synchronisation")
-        result["cpu_baseline"]["config1_drop_in_steps_per_s"] = drate
-        result["cpu_baseline"]["config1_reference_style_python_steps_per_s"] = prate
-        # the last CPU pass doubles as a full-size parity check of what the GPU just computed
-        one_step(W + passes - 1)
-        torch.cuda.synchronize()
-        assert np.array_equal(out.cpu().numpy(), bo_) and np.array_equal(flags.cpu().numpy(), fo_), "GPU != oracle"
-        if not args.no_beam:
-            hr = roots.cpu().numpy()
-
-            def time_beam(threads, seconds, cap):
+            def time_steps(threads, seconds):
                 O.set_num_threads(threads)
-                c0 = time.perf_counter(); cexp = 0; cdec = 0; last = None
-                while time.perf_counter() - c0 < seconds and cdec < cap:
-                    last = O.beam_batch(hr if threads > 1 else hr[:256], BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec,
-                                        game_id_base=0)
-                    cexp += int(last[2].sum()); cdec += 1
-                return cexp, cdec, time.perf_counter() - c0, last
-            e1, d1, sec1, _ = time_beam(1, args.cpu_seconds * 0.3, 100)
-            ea, da, seca, _ = time_beam(every, args.cpu_seconds * 0.3, 100) if every > many else (0, 0, 1.0, None)
-            cexp, cdec, csec, (oa, op, oe) = time_beam(many, args.cpu_seconds * 0.5, 100)
-            result["beam"]["cpu_baseline"] = {"value": cexp / csec, "unit": "expansions/s",
-                                              "cores": O.num_threads(), "kind": "port",
-                                              "sample": "%d batch decisions over the same 4096 roots (%.1f s, OpenMP "
-                                                        "dynamic over games)" % (cdec, csec),
-                                              "one_thread": {"value": e1 / sec1, "cores": 1,
-                                                             "sample": "%d batch decisions over the first 256 roots, %.1f s" % (d1, sec1)},
-                                              "all_affinity_cores": ({"value": ea / seca, "cores": every,
-                                                                      "sample": "%d batch decisions over the same 4096 roots, %.1f s"
-                                                                                % (da, seca)} if every > many else None),
-                                              **info}
-            cb = result["beam"]["cpu_baseline"]
-            result["cpu_baseline"]["beam"] = {"value": cb["value"], "unit": "expansions/s", "cores": cb["cores"], "kind": "port",
-                                              "one_thread": cb["one_thread"]["value"], "sample": cb["sample"]}
-            result["cpu_baseline"]["beam_value"], result["cpu_baseline"]["beam_cores"] = cb["value"], cb["cores"]
-            result["cpu_baseline"]["beam_one_thread_value"] = cb["one_thread"]["value"]
-            result["cpu_baseline"]["one_thread_value"] = result["cpu_baseline"]["one_thread"]["value"]
-            a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
-                                          game_id_base=0, want_expanded=True)
-            assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(e.cpu().numpy().astype(np.uint32), oe), \
-                "GPU beam != oracle"
+                c0 = time.perf_counter(); passes = 0; last = None
+                while time.perf_counter() - c0 < seconds and passes < 1000:
+                    last = O.step_batch(hb, ha, hs, seed=SEED, step_index=W + passes, id_base=id_base)
+                    passes += 1
+                return passes, time.perf_counter() - c0, last
+            # libgomp is already loaded by torch, so OMP_NUM_THREADS is moot: size the pool explicitly to the box's CPU
+            # share (16 for one GPU) or to the cores this process may run on, whichever is smaller
+            many = min(16, info["affinity"])
+            every = min(info["affinity"], 512)      # all the host cores this process may run on ("1 core and all host cores")
+            p1, s1, _ = time_steps(1, args.cpu_seconds * 0.35)
+            pa, sa, _ = time_steps(every, args.cpu_seconds * 0.25) if every > many else (0, 1.0, None)
+            passes, csec, (bo_, so_, ro_, fo_) = time_steps(many, args.cpu_seconds * 0.4)
+            result["cpu_baseline"] = {"value": n * passes / csec, "unit": "board-steps/s", "cores": O.num_threads(),
+                                      "kind": "port",
+                                      "sample": "%d passes of g2048o_step_batch over the same 1,048,576 boards "
+                                                "(%.1f s, OpenMP static over boards)" % (passes, csec),
+                                      "one_thread": {"value": n * p1 / s1, "cores": 1,
+                                                     "sample": "%d passes, %.1f s" % (p1, s1)},
+                                      "all_affinity_cores": ({"value": n * pa / sa, "cores": every,
+                                                              "sample": "%d passes, %.1f s, one OpenMP thread per core in the affinity mask "
+                                                                        "(slower than `value` where the box's CPU share is smaller than the mask: "
+                                                                        "see cgroup_cpu_quota_cores)" % (pa, sa)} if every > many else None),
+                                      **info}
+            from oracle import pyref
+            prate = pyref.time_steps(4000, SEED)
+            result["cpu_baseline_python"] = {"value": prate, "unit": "board-steps/s", "cores": 1, "kind": "port",
+                                             "sample": "4000 steps of one board, reference-style per-board NumPy env "
+                                                       "(oracle/pyref.py), auto-reset",
+                                             "calibration": "the reference's own Game2048Env ran at 0.88x this env's rate on "
+                                                            "the same core in the build container (2.55e3 vs 2.92e3 steps/s)"}
+            # config 1 (the reference's own CPU-runnable case) through the drop-in class: a train.py-shaped iteration
+            # (get_valid_moves + step, train.py:55-75) = one g2048_env_step launch + one synchronisation
+            from environment.game_2048 import Game2048Env
+            denv = Game2048Env(seed=SEED)
+            for i in range(200):
+                denv.get_valid_moves(); denv.step(i & 3)
+            d0 = time.perf_counter(); dsteps = 0
+            while dsteps < 4000:
+                denv.get_valid_moves()
+                if denv.step(dsteps & 3)[2]:
+                    denv.reset()
+                dsteps += 1
+            drate = dsteps / (time.perf_counter() - d0)
+            result["cpu_baseline_python"]["drop_in_steps_per_s"] = drate
+            result["cpu_baseline_python"]["drop_in_note"] = ("environment.game_2048.Game2048Env on the GPU, one board, get_valid_moves() + step() "
+                                                             "per iteration: one g2048_env_step launch + one synchronisation")
+            result["cpu_baseline"]["config1_drop_in_steps_per_s"] = drate
+            result["cpu_baseline"]["config1_reference_style_python_steps_per_s"] = prate
+            # the last CPU pass doubles as a full-size parity check of what the GPU just computed
+            one_step(W + passes - 1)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), bo_) and np.array_equal(flags.cpu().numpy(), fo_), "GPU != oracle"
+            if not args.no_beam:
+                hr = roots.cpu().numpy()
+
+                def time_beam(threads, seconds, cap):
+                    O.set_num_threads(threads)
+                    c0 = time.perf_counter(); cexp = 0; cdec = 0; last = None
+                    while time.perf_counter() - c0 < seconds and cdec < cap:
+                        last = O.beam_batch(hr if threads > 1 else hr[:256], BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec,
+                                            game_id_base=0)
+                        cexp += int(last[2].sum()); cdec += 1
+                    return cexp, cdec, time.perf_counter() - c0, last
+                e1, d1, sec1, _ = time_beam(1, args.cpu_seconds * 0.3, 100)
+                ea, da, seca, _ = time_beam(every, args.cpu_seconds * 0.3, 100) if every > many else (0, 0, 1.0, None)
+                cexp, cdec, csec, (oa, op, oe) = time_beam(many, args.cpu_seconds * 0.5, 100)
+                result["beam"]["cpu_baseline"] = {"value": cexp / csec, "unit": "expansions/s",
+                                                  "cores": O.num_threads(), "kind": "port",
+                                                  "sample": "%d batch decisions over the same 4096 roots (%.1f s, OpenMP "
+                                                            "dynamic over games)" % (cdec, csec),
+                                                  "one_thread": {"value": e1 / sec1, "cores": 1,
+                                                                 "sample": "%d batch decisions over the first 256 roots, %.1f s" % (d1, sec1)},
+                                                  "all_affinity_cores": ({"value": ea / seca, "cores": every,
+                                                                          "sample": "%d batch decisions over the same 4096 roots, %.1f s"
+                                                                                    % (da, seca)} if every > many else None),
+                                                  **info}
+                cb = result["beam"]["cpu_baseline"]
+                result["cpu_baseline"]["beam"] = {"value": cb["value"], "unit": "expansions/s", "cores": cb["cores"], "kind": "port",
+                                                  "one_thread": cb["one_thread"]["value"], "sample": cb["sample"]}
+                result["cpu_baseline"]["beam_value"], result["cpu_baseline"]["beam_cores"] = cb["value"], cb["cores"]
+                result["cpu_baseline"]["beam_one_thread_value"] = cb["one_thread"]["value"]
+                result["cpu_baseline"]["one_thread_value"] = result["cpu_baseline"]["one_thread"]["value"]
+                a, p, e = ops.beam_get_action(roots, BEAM_WIDTH, BEAM_DEPTH, seed=SEED, step_index=10 + cdec - 1,
+                                              game_id_base=0, want_expanded=True)
+                assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(e.cpu().numpy().astype(np.uint32), oe), \
+                    "GPU beam != oracle"
+
+    if world == 1:
+        _optional_legs()
+    else:
+        try:
+            _optional_legs()
+        except Exception as exc:            # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            text = str(exc).strip().splitlines()
+            result["optional_legs_error"] = "%s: %s" % (type(exc).__name__, text[0][:300] if text else "")
 
     if rank == 0:
         # the numbers of BASELINE's two-part metric once more at the END of the line (a log that keeps only a tail keeps these)
