@@ -56,12 +56,12 @@ constexpr int kRolloutBlock = 128;
 // LDS: the direction selectors (g2048_board.h "direction by table") and the 18 possible observation values
 // float32(code) / float32(15); every wave fills both itself (same values from every wave, own write before own read).
 __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
-    const uint4 *boards_in, const float4 *__restrict__ probs, const uint8_t *__restrict__ mask_in, uint4 *boards_out,
-    uint32_t *__restrict__ score, uint8_t *__restrict__ actions_out, float *__restrict__ prob_out,
+    // (the first 14 dwords -- what a wavefront needs before its loads can go out -- arrive preloaded in SGPRs: g2048/_build.py)
+    size_t n, const uint4 *boards_in, const float4 *__restrict__ probs, uint32_t *__restrict__ score,
+    const uint8_t *__restrict__ mask_in, const unsigned long long *__restrict__ step_counter, uint64_t seed,
+    uint64_t step_index, uint64_t id_base, uint4 *boards_out, uint8_t *__restrict__ actions_out, float *__restrict__ prob_out,
     void *__restrict__ reward_out, uint8_t *__restrict__ flags_out, void *__restrict__ obs_next,
-    uint8_t *__restrict__ mask_next, uint4 *__restrict__ next_boards_out, uint8_t *__restrict__ state_max_out,
-    uint64_t seed, uint64_t step_index, const unsigned long long *__restrict__ step_counter, uint64_t id_base, size_t n,
-    uint32_t opts)
+    uint8_t *__restrict__ mask_next, uint4 *__restrict__ next_boards_out, uint8_t *__restrict__ state_max_out, uint32_t opts)
 {
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
     __shared__ float s_obs[32];
@@ -446,10 +446,11 @@ int g2048_rollout_step(const void *boards_in, const float *probs, const uint8_t 
         (obs_next_out_or_null && !aligned(obs_next_out_or_null, 16)) || (step_counter_or_null && !aligned(step_counter_or_null, 8)))
         return fail(G2048_ERR_ARG, "g2048_rollout_step: misaligned array");
     hipLaunchKernelGGL(rollout_step_kernel, dim3((unsigned)((n + kRolloutBlock - 1) / kRolloutBlock)), dim3(kRolloutBlock), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const uint4 *>(boards_in), reinterpret_cast<const float4 *>(probs),
-                       mask4_in_or_null, static_cast<uint4 *>(boards_out), score_inout, actions_out, prob_out, reward_out, flags_out,
+                       static_cast<hipStream_t>(stream), n, static_cast<const uint4 *>(boards_in), reinterpret_cast<const float4 *>(probs),
+                       score_inout, mask4_in_or_null, step_counter_or_null, seed, step_index, env_id_base,
+                       static_cast<uint4 *>(boards_out), actions_out, prob_out, reward_out, flags_out,
                        obs_next_out_or_null, mask4_next_out_or_null, static_cast<uint4 *>(next_boards_out_or_null),
-                       state_maxcode_out_or_null, seed, step_index, step_counter_or_null, env_id_base, n, opts);
+                       state_maxcode_out_or_null, opts);
     return check_launch("g2048_rollout_step");
 }
 

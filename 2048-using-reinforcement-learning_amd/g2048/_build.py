@@ -16,7 +16,11 @@ SOURCES = ["g2048_kernels.hip", "g2048_beam.hip", "g2048_rollout.hip"]
 INCLUDE = os.path.join(CSRC, "..", "..", "include")
 PUBLIC_HEADERS = [os.path.join(INCLUDE, "g2048.h"), os.path.join(INCLUDE, "g2048_testing.h")]
 # -fvisibility=hidden: the export table is exactly what the two headers declare with G2048_API (tests/test_abi_and_host.py)
+# -amdgpu-kernarg-preload-count: the first kernel-argument dwords arrive in SGPRs with the wavefront instead of through s_load +
+# s_waitcnt at its head (gfx950 takes up to 14 next to the kernarg pointer; the short kernels order their arguments for it:
+# 12.9 -> 12.55 us per 1 Mi-board step launch, profiles/r05_kernel_heads.txt)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
          "-Wl,--version-script=" + os.path.join(CSRC, "g2048_exports.map"), "-Wall", "-Wno-unused-function"]
 
 
