@@ -510,24 +510,44 @@ G2048_HD double reward_env(const Board &cur, const TileStats &st, uint32_t gain,
 // sum equals (gain - 8*[invalid] + 2*(after - before)) * 0.25 exactly -- one conversion and one multiply.
 // (Round 3 tried the four products (double)c * 0.1 from an 8-entry LDS table: the table fill and the address arithmetic cost
 // more than the conversions and multiplications they replace: 386 against 374 static instructions. Not kept.)
+// `tenth(c)` supplies (double)c * 0.1 for the ordered-pair counts c = 0 .. 6 of :267-275: the product itself by default, or -- in
+// the kernels that keep the direction table in LDS anyway -- a read of the eight products from the same table (an address shift and
+// an LDS read instead of a conversion and an f64 multiply on the VALU, which is what bounds the step; the values are the same
+// IEEE products, computed by the host compiler: G2048_TENTHS_INIT).
+// Interface: kColShift = the right shift that turns a 0x80 byte flag into a column count's unit (7: counts; 4: counts * 8, a byte
+// offset into a table of doubles), operator()(row pairs, column pairs in that unit) -> (double)(row + col) * 0.1.
+// crowded(r, empty_after) applies :263-264 (`if empty_after <= 2: reward -= 2.0`): the subtraction by default, or r + T[empty_after]
+// with T = {-2, -2, -2, 0, 0, ...} from the same table (r is never -0.0 at that point -- a sum whose last term is the non-negative
+// quotient -- so adding +0.0 leaves every bit alone).
+struct TenthByProduct {
+    static constexpr uint32_t kColShift = 7u;
+    G2048_HD double operator()(uint32_t rows, uint32_t cols) const { return (double)(rows + cols) * 0.1; }
+    G2048_HD double crowded(double r, uint32_t empty_after) const { return empty_after <= 2u ? r - 2.0 : r; }
+};
+
+#define G2048_TENTHS 8
+#define G2048_TENTHS_INIT { 0.0 * 0.1, 1.0 * 0.1, 2.0 * 0.1, 3.0 * 0.1, 4.0 * 0.1, 5.0 * 0.1, 6.0 * 0.1, 7.0 * 0.1 }
+#define G2048_CROWDED 17
+#define G2048_CROWDED_INIT { -2.0, -2.0, -2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 }
+
+template <class TENTH = TenthByProduct>
 G2048_HD double reward_env_folded(const Board &cur, const TileStats &st, uint32_t gain, bool valid,
-                                  uint32_t empty_before, uint32_t empty_after)
+                                  uint32_t empty_before, uint32_t empty_after, TENTH tenth = TENTH())
 {
     const int32_t q = (int32_t)gain - (valid ? 0 : 8) + 2 * ((int32_t)empty_after - (int32_t)empty_before);
     double r = (double)q * 0.25;
     r += div_small_ints((double)st.edge, (double)st.total) * 1.0;
-    if (empty_after <= 2u) r -= 2.0;
+    r = tenth.crowded(r, empty_after);
     const uint32_t n0 = nzflag(cur.w[0]), n1 = nzflag(cur.w[1]), n2 = nzflag(cur.w[2]), n3 = nzflag(cur.w[3]);
     const uint32_t v01 = geflag(cur.w[1], cur.w[0]) & n0 & n1;
     const uint32_t v12 = geflag(cur.w[2], cur.w[1]) & n1 & n2;
     const uint32_t v23 = geflag(cur.w[3], cur.w[2]) & n2 & n3;
-    const uint32_t colcnt = (v01 >> 7) + (v12 >> 7) + (v23 >> 7);
+    const uint32_t colcnt = (v01 >> TENTH::kColShift) + (v12 >> TENTH::kColShift) + (v23 >> TENTH::kColShift);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t x = cur.w[i], n = i == 0 ? n0 : i == 1 ? n1 : i == 2 ? n2 : n3;
         const uint32_t h = geflag(x >> 8, x) & n & (n >> 8);                  // (n >> 8 has no flag in byte 3)
-        const uint32_t c = popc(h) + ((colcnt >> (8 * i)) & 0xffu);
-        r += (double)c * 0.1;
+        r += tenth(popc(h), (colcnt >> (8 * i)) & 0xffu);
     }
     return r;
 }
@@ -558,8 +578,8 @@ G2048_HD bool game_over_counted(const Board &b, uint32_t n_empty)
 struct StepOut { Board board; uint32_t gain; double reward; uint32_t flags; };
 
 // MOVE: a callable (const Board &, uint32_t &gain, uint32_t &merges) -> Board doing the env move
-template <class MOVE>
-G2048_HD StepOut step_board_with(const Board &prev, MOVE move, uint32_t h)
+template <class MOVE, class TENTH = TenthByProduct>
+G2048_HD StepOut step_board_with(const Board &prev, MOVE move, uint32_t h, TENTH tenth = TENTH())
 {
     StepOut o;
     uint32_t merges;
@@ -573,7 +593,7 @@ G2048_HD StepOut step_board_with(const Board &prev, MOVE move, uint32_t h)
     const uint32_t empty_before = empty_mid - merges;
     const uint32_t empty_after = empty_mid - (valid ? 1u : 0u);
     const TileStats st = tile_stats_z(cur, empty_after, zf[0], zf[1], zf[2], zf[3]);
-    o.reward = reward_env_folded(cur, st, o.gain, valid, empty_before, empty_after);
+    o.reward = reward_env_folded(cur, st, o.gain, valid, empty_before, empty_after, tenth);
     const bool done = game_over_counted(cur, empty_after);
     const uint32_t maxcode = 31u - (uint32_t)__builtin_clz(st.orbits | 1u);
     o.flags = (done ? 1u : 0u) | (valid ? 2u : 0u) | (maxcode << 3);
@@ -588,19 +608,21 @@ G2048_HD StepOut step_board(const Board &prev, uint32_t action, uint32_t h)
 
 // An action outside 0..3 moves nothing in the reference (_execute_move, environment/game_2048.py:97-114, has no branch for
 // it), so the step is an invalid move: no spawn, the -2.0 of :226-227. noop = "this lane's action is such a value".
-G2048_HD StepOut step_board_sel_noop(const Board &prev, const DirSel &sel, bool noop, uint32_t h)
+template <class TENTH = TenthByProduct>
+G2048_HD StepOut step_board_sel_noop(const Board &prev, const DirSel &sel, bool noop, uint32_t h, TENTH tenth = TENTH())
 {
     return step_board_with(prev, [&sel, noop](const Board &b, uint32_t &g, uint32_t &m) {
         const Board r = move_env_sel(b, sel, g, m);
         g = noop ? 0u : g; m = noop ? 0u : m;
         return Board{{noop ? b.w[0] : r.w[0], noop ? b.w[1] : r.w[1], noop ? b.w[2] : r.w[2], noop ? b.w[3] : r.w[3]}};
-    }, h);
+    }, h, tenth);
 }
 
 // the same step with the direction given as its selector words (see "direction by table")
-G2048_HD StepOut step_board_sel(const Board &prev, const DirSel &sel, uint32_t h)
+template <class TENTH = TenthByProduct>
+G2048_HD StepOut step_board_sel(const Board &prev, const DirSel &sel, uint32_t h, TENTH tenth = TENTH())
 {
-    return step_board_with(prev, [&sel](const Board &b, uint32_t &g, uint32_t &m) { return move_env_sel(b, sel, g, m); }, h);
+    return step_board_with(prev, [&sel](const Board &b, uint32_t &g, uint32_t &m) { return move_env_sel(b, sel, g, m); }, h, tenth);
 }
 
 // ---------------------------------------------------------------- policy ------

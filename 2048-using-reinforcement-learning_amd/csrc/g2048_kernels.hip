@@ -55,23 +55,12 @@ inline unsigned blocks_for(size_t n, int per_block = kBlock) { return (unsigned)
 // ds_read_b128.
 __device__ const uint32_t kDirTable[G2048_DIR_TABLE_WORDS] = G2048_DIR_TABLE_INIT;
 
+#include "g2048_step_table.h"
+
 __device__ __forceinline__ void dir_table_to_lds(uint4 *s_dir)
 {
     const uint32_t l = threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u);          // both halves of the wave write the same 32 words:
     reinterpret_cast<uint32_t *>(s_dir)[l] = kDirTable[l];                    // no exec masking, no branch
-}
-
-// The same in two halves, so that a kernel can put its own loads BETWEEN the table word's load and its LDS write: the write has
-// to wait for the word, and loads issued only after it would start a second memory round trip at the head of every wavefront
-// (the compiler does not move a global load up across the write). Every lane of the wavefront must run both halves.
-__device__ __forceinline__ uint32_t dir_table_word()
-{
-    return kDirTable[threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u)];
-}
-
-__device__ __forceinline__ void dir_table_store(uint4 *s_dir, uint32_t word)
-{
-    reinterpret_cast<uint32_t *>(s_dir)[threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u)] = word;
 }
 
 __device__ __forceinline__ DirSel dir_sel(const uint4 *s_dir, uint32_t action)
@@ -79,8 +68,6 @@ __device__ __forceinline__ DirSel dir_sel(const uint4 *s_dir, uint32_t action)
     const uint4 i = s_dir[2u * action], o = s_dir[2u * action + 1u];
     return DirSel{i.x, i.y, i.z, i.w, o.x, o.y, o.z, o.w};
 }
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: volatile 16-byte loads stay ONE global_load_dwordx4)
 
 __device__ __forceinline__ Board load_board(const uint4 *p, size_t i)
 {
@@ -120,8 +107,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
     [[maybe_unused]] const unsigned long long tm0 = kStepTiming ? wall_clock64() : 0ull;       // (measurement builds only, tools/step_timeline.py)
     if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
-    __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
-    const uint32_t dir_word = dir_table_word();                   // (stored to LDS below, once the lane's own loads are on their way)
+    __shared__ uint4 s_dir[kStepTableWords / 4];
+    const uint2 dir_word = step_table_word();                     // (stored to LDS below, once the lane's own loads are on their way)
+    const TenthFromLds tenth{reinterpret_cast<const StepTable *>(s_dir)};
     // per-block scalar bases + a 32-bit lane offset: the 7 streams are addressed as SGPR base + VGPR offset
     const size_t block0 = (size_t)blockIdx.x * (BLOCK * B);
     const uint4 *bin = boards_in + block0;
@@ -145,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
         if (!RANDOM_ACTIONS) action[k] = act[j];
         sc[k] = scp[j];
     }
-    dir_table_store(s_dir, dir_word);
+    step_table_store(s_dir, dir_word);
     if (B > 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < B; ++k) {
@@ -153,8 +141,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
         if (B > 1 && !(full || j < lim)) break;
         const uint64_t id = id_base + block0 + j;
         if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
-        const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u))
-                                       : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u));
+        const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u), tenth)
+                                       : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u), tenth);
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
         if (AUTO_RESET) {
@@ -195,6 +183,8 @@ __global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in
                                                           uint64_t seed, uint64_t step_index0, uint32_t steps, uint64_t id_base,
                                                           size_t n)
 {
+    // (the reward's constants stay arithmetic here: with them read from LDS the compiler no longer sinks the reward into the
+    // `if (reward_stream)` branch, and a launch without a reward stream pays for it -- 7.9 -> 8.9 us per step, measured)
     __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
     dir_table_to_lds(s_dir);
     // per-block scalar bases + a 32-bit lane offset, as in step_kernel; the streams advance by n per step on the scalar unit

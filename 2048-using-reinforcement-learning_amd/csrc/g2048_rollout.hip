@@ -48,7 +48,7 @@ int check_launch(const char *what)
 
 inline bool aligned(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1u)) == 0; }
 
-__device__ const uint32_t kDirTable[G2048_DIR_TABLE_WORDS] = G2048_DIR_TABLE_INIT;
+#include "g2048_step_table.h"
 
 constexpr int kRolloutBlock = 128;
 
@@ -63,15 +63,15 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
     void *__restrict__ reward_out, uint8_t *__restrict__ flags_out, void *__restrict__ obs_next,
     uint8_t *__restrict__ mask_next, uint4 *__restrict__ next_boards_out, uint8_t *__restrict__ state_max_out, uint32_t opts)
 {
-    __shared__ uint4 s_dir[G2048_DIR_TABLE_WORDS / 4];
-    __shared__ float s_obs[32];
+    __shared__ uint4 s_dir[kStepTableWords / 4];             // selector words + the reward's f64 constants + the observation values
+    const float *const s_obs = reinterpret_cast<const StepTable *>(s_dir)->obs;
+    const TenthFromLds tenth{reinterpret_cast<const StepTable *>(s_dir)};
     // At 65,536 envs a SIMD holds ONE wavefront: whatever it waits for, nothing else runs meanwhile. So everything the wavefront
     // reads goes out at once -- the direction table's word, the lane's board / probabilities / score / mask (every lane loads:
     // the lanes past the end a clamped, valid index whose data they drop, so that no exec region separates the loads from
     // the table's LDS write below) and the step counter -- and the head of the wavefront is one memory round trip, not three
     // (table word -> LDS write; counter -> keys; lane data).
-    const uint32_t l32 = threadIdx.x & (G2048_DIR_TABLE_WORDS - 1u);
-    const uint32_t dir_word = kDirTable[l32];
+    const uint2 table_word = step_table_word();
     const size_t i = (size_t)blockIdx.x * kRolloutBlock + threadIdx.x;
     const size_t ic = i < n ? i : n - 1u;
     const uint4 pv = boards_in[ic];
@@ -81,8 +81,7 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
     // keys of this step: uniform, derived on the scalar unit from (seed, domain, step index); the index may come from a
     // device counter so that a captured hipGraph of a whole rollout can be replayed
     const uint64_t index = step_index + (step_counter ? (uint64_t)*step_counter : 0ull);
-    reinterpret_cast<uint32_t *>(s_dir)[l32] = dir_word;      // both halves of the wave write the same 32 words: no branch
-    s_obs[l32] = (float)l32 / 15.0f;                          // IEEE f32 quotient, once per wave
+    step_table_store(s_dir, table_word);
     const Keys kp = rng_keys(seed, DOM_POLICY, index), ks = rng_keys(seed, DOM_STEP, index), ke = rng_keys(seed, DOM_EPISODE, index);
     const uint64_t id = id_base + i;
     const Board prev = {{pv.x, pv.y, pv.z, pv.w}};
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(kRolloutBlock) void rollout_step_kernel(
     float pa;
     const uint32_t a = sample_action(p.x, p.y, p.z, p.w, mask, rng_draw(kp.k0, kp.k1, id, 0u), pa);
     const uint4 si = s_dir[2u * a], so = s_dir[2u * a + 1u];
-    const StepOut o = step_board_sel(prev, DirSel{si.x, si.y, si.z, si.w, so.x, so.y, so.z, so.w}, rng_draw(ks.k0, ks.k1, id, 0u));
+    const StepOut o = step_board_sel(prev, DirSel{si.x, si.y, si.z, si.w, so.x, so.y, so.z, so.w}, rng_draw(ks.k0, ks.k1, id, 0u), tenth);
     if (i >= n) return;                                      // (the lanes past the end computed on their clamped loads; they store nothing)
     if (next_boards_out) next_boards_out[i] = make_uint4(o.board.w[0], o.board.w[1], o.board.w[2], o.board.w[3]);
     if (state_max_out) state_max_out[i] = (uint8_t)max_code(prev);
