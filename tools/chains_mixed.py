@@ -61,6 +61,33 @@ def mixed():
     sc.join()
 
 
+# both chains' steps P..K-1 as linear graphs, steps 0..P-1 as plain alternating launches that keep the GPU busy while the graphs
+# are being launched
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+tails = []
+for c in range(2):
+    cs = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(g, stream=cs, capture_error_mode="thread_local"):
+            for t in range(P, K):
+                calls[c](t, cs.cuda_stream)
+    tails.append(g)
+torch.cuda.synchronize()
+
+
+def prefix_then_graphs():
+    sc.fork()
+    lanes = [(call, sc.stream(c).cuda_stream) for c, call in enumerate(calls)]
+    for t in range(P):
+        for call, sp in lanes:
+            call(t, sp)
+    for c in range(2):
+        with torch.cuda.stream(sc.stream(c)):
+            tails[c].replay()
+    sc.join()
+
+
 def measure(name, run):
     run()
     torch.cuda.synchronize()
@@ -89,4 +116,6 @@ print("%s: K = %d steps of 1,048,576 boards as two chains from an idle stream, o
 for rnd in range(3):
     ref = measure("both chains plain launches, alternating", alternating)
     got = measure("chain 1 from a linear hipGraph, chain 0 plain", mixed)
+    assert torch.equal(ref, got), "scores differ"
+    got = measure("%d plain steps, then one linear graph per chain" % P, prefix_then_graphs)
     assert torch.equal(ref, got), "scores differ"
