@@ -25,10 +25,16 @@ OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "gpurun_out")
 PROF = os.path.join(REPO, "profiles")
 
 
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/: a pass directory can hold the files of earlier runs too. Only the newest set."""
+    files = glob.glob(pattern, recursive=True)
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 def counters(pass_name):
     """{kernel name: {counter: (n, mean)}} of one pass."""
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(OUT, "prof_%s_%s" % (TAG, pass_name), "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(OUT, "prof_%s_%s" % (TAG, pass_name), "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return {k: {c: (len(v), sum(v) / len(v)) for c, v in cs.items()} for k, cs in acc.items()}
@@ -36,7 +42,7 @@ def counters(pass_name):
 
 def durations(pass_name, grid=None):
     by = defaultdict(list)
-    for f in glob.glob(os.path.join(OUT, "prof_%s_%s" % (TAG, pass_name), "**", "*kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(OUT, "prof_%s_%s" % (TAG, pass_name), "**", "*kernel_trace.csv")):
         for row in csv.DictReader(open(f)):
             g = row.get("Grid_Size") or row.get("Grid_Size_X")
             if grid is None or str(grid) == g:
