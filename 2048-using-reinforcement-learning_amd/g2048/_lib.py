@@ -14,7 +14,7 @@ from . import _build
 _lib = None
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_DONE, FLAG_VALID, FLAG_MAXCODE_SHIFT = 0x01, 0x02, 3
 STEP_REWARD_F64, STEP_AUTO_RESET, STEP_RANDOM_ACTIONS, STEP_NOOP_ACTIONS = 0x01, 0x02, 0x04, 0x08
 VALID_ENV, VALID_AGENT = 0, 1

@@ -45,7 +45,9 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 4        /* 4: round 5 (export table = this header + g2048_testing.h exactly: test / measurement hooks moved there,
+#define G2048_ABI_VERSION 5        /* 5: round 5, second half (ops MOVE / SPAWN / MOVE_AGENT of g2048_env_step; g2048_eval kinds CORNER_BONUS and
+                                      MERGE_POTENTIAL; no entry point added or removed)
+                                      4: round 5 (export table = this header + g2048_testing.h exactly: test / measurement hooks moved there,
                                       internal symbols hidden; g2048_replay_games also clamps a game's length to actions_stride)
                                       3: round 4 (actions_out of the g2048_play_games family, g2048_replay_games, g2048_env_step,
                                       g2048_minibatch_gather, g2048_build_flags; the A/B variants of g2048_step / g2048_sort_selftest gone)

@@ -13,6 +13,10 @@ __global__ void k15(size_t n, const uint32_t *kb, const uint4 *in, const uint8_t
                     uint4 *out, void *reward, uint8_t *flags, uint32_t e0, uint32_t e1, uint32_t a0, uint32_t a1)
 {
     if (threadIdx.x == 0 && n == 12345) score[0] = k0 + k1 + e0 + e1 + a0 + a1 + (uint32_t)id_base;
+    if (a1 > 6u) {                               // busy variant: ~a1 x 64 ns of work per launch, so that the queues are never empty
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)a1 * 6400ull / 1000ull) { }
+    }
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -42,6 +46,28 @@ int main()
         t1 = now();
         CK(hipDeviceSynchronize());
         printf("hipLaunchKernelGGL, one stream:                 %.2f us per launch\n", (t1 - t0) * 1e6 / K);
+
+        // the same with stream 0 of the pair being the NULL stream (what torch.cuda.current_stream() is outside a stream context)
+        hipStream_t sn[2] = {nullptr, s[1]};
+        t0 = now();
+        for (int w = 0; w < K; ++w) hipLaunchKernelGGL(k15, dim3(1), dim3(64), 0, sn[w & 1], n, kb, in, act, score, idb, k0, k1, out, rw, fl, e0, e1, a0, a1);
+        t1 = now();
+        CK(hipDeviceSynchronize());
+        printf("hipLaunchKernelGGL, NULL stream / non-blocking stream alternating: %.2f us per launch\n", (t1 - t0) * 1e6 / K);
+        // busy kernels (~5 us each): 40 launches from idle, as the bench's timed region
+        for (int busy = 0; busy < 2; ++busy) {
+            hipStream_t *ss = busy ? sn : s;
+            double acc = 0;
+            for (int r = 0; r < 50; ++r) {
+                CK(hipDeviceSynchronize());
+                t0 = now();
+                for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(k15, dim3(1), dim3(64), 0, ss[w & 1], n, kb, in, act, score, idb, k0, k1, out, rw, fl, e0, e1, a0, 800u);
+                t1 = now();
+                acc += t1 - t0;
+            }
+            CK(hipDeviceSynchronize());
+            printf("  40 busy (5 us) launches from idle, %s: %.2f us of host time per launch\n", busy ? "NULL / non-blocking" : "two non-blocking streams", acc * 1e6 / 50 / 40);
+        }
 
         hipFunction_t f;
         CK(hipGetFuncBySymbol(&f, (const void *)k15));
