@@ -405,6 +405,17 @@ G2048_HD uint32_t rng_draw(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr)
     return h;
 }
 
+// The same draw for a caller whose ids share their high word (a launch that does not cross a multiple of 2^32: the host splits
+// one that would): k1h = k1 + rng_hi_term(id) (g2048_rng.h) is formed once, on the host or the scalar unit, and the lane hashes 32 bits.
+G2048_HD uint32_t rng_draw_lo(uint32_t k0, uint32_t k1h, uint32_t id_lo, uint32_t ctr)
+{
+    uint32_t h = id_lo ^ k0;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += k1h + ctr * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
 // --------------------------------------------------------------- tile sums ----
 struct TileStats {
     uint32_t total;      // sum of tile values

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
                                                      const uint4 *boards_in,       // may alias boards_out
                                                      const uint8_t *__restrict__ actions,
                                                      uint32_t *__restrict__ score,
-                                                     uint64_t id_base, uint32_t k0, uint32_t k1,
+                                                     uint32_t id_lo_base, uint32_t id_hi_term, uint32_t k0, uint32_t k1,
                                                      // (the first 14 dwords -- everything the head of a wavefront needs before its loads
                                                      // can go out -- arrive preloaded in SGPRs: -amdgpu-kernarg-preload-count, g2048/_build.py)
                                                      uint4 *boards_out,
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
     [[maybe_unused]] const unsigned long long tm0 = kStepTiming ? wall_clock64() : 0ull;       // (measurement builds only, tools/step_timeline.py)
     if (B > 1) __builtin_amdgcn_s_setprio(3);
     if (keyblock) { k0 = keyblock[KB_STEP]; k1 = keyblock[KB_STEP + 1]; e0 = keyblock[KB_EPISODE]; e1 = keyblock[KB_EPISODE + 1]; }
+    // the ids of one launch share their high word (step_impl splits a launch that would cross a multiple of 2^32), so its term of
+    // the draw is folded into the second key word here, on the scalar unit, and a lane hashes its id's low word only (rng_draw_lo)
+    k1 += id_hi_term; e1 += id_hi_term; a1 += id_hi_term;
     __shared__ uint4 s_dir[kStepTableWords / 4];
     const uint2 dir_word = step_table_word();                     // (stored to LDS below, once the lane's own loads are on their way)
     const TenthFromLds tenth{reinterpret_cast<const StepTable *>(s_dir)};
@@ -119,8 +122,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
     uint8_t *flp = flags_out + block0;
     float *rw32 = static_cast<float *>(reward_out) + block0;
     double *rw64 = static_cast<double *>(reward_out) + block0;
-    const bool full = block0 + (size_t)(BLOCK * B) <= n;          // wave-uniform: every lane of the block is in range
-    const uint32_t lim = full ? (uint32_t)(BLOCK * B) : (uint32_t)(n - block0);
+    // boards of this block that exist (32-bit scalar arithmetic: a 64-bit unsigned compare would run on the VALU)
+    const uint64_t rem = (uint64_t)n - block0;
+    uint32_t rem_hi = (uint32_t)(rem >> 32);
+    const uint32_t rem_lo = (uint32_t)rem;
+    asm volatile("" : "+s"(rem_hi));             // (kept apart on purpose: recombined, the test is a 64-bit compare, which only the VALU has)
+    const uint32_t lim = rem_hi != 0u ? (uint32_t)(BLOCK * B) : min(rem_lo, (uint32_t)(BLOCK * B));
+    const bool full = lim == (uint32_t)(BLOCK * B);               // wave-uniform: every lane of the block is in range
     // Every lane loads -- the lanes past the end of a ragged last block a clamped (valid) index whose data they drop -- so that
     // the loads need no exec region and go out BEFORE the direction table's LDS write waits for its word: one memory round trip
     // at the head of a wavefront, not two.
@@ -137,23 +145,25 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(size_t n, const uint32_t *_
     if (B > 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        const uint32_t j = threadIdx.x + (uint32_t)k * BLOCK;
+        // (B == 1: the clamped index serves the stores too -- the same offsets as the loads' -- since the lanes it differs for leave
+        // before them)
+        const uint32_t j = B == 1 ? min(threadIdx.x, lim - 1u) : threadIdx.x + (uint32_t)k * BLOCK;
         if (B > 1 && !(full || j < lim)) break;
-        const uint64_t id = id_base + block0 + j;
-        if (RANDOM_ACTIONS) action[k] = rng_draw(a0, a1, id, 0u) >> 30;       // what g2048_synth_actions would write
-        const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw(k0, k1, id, 0u), tenth)
-                                       : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw(k0, k1, id, 0u), tenth);
+        const uint32_t id = id_lo_base + (uint32_t)block0 + j;           // low word of the board id (the launch never wraps it)
+        if (RANDOM_ACTIONS) action[k] = rng_draw_lo(a0, a1, id, 0u) >> 30;    // what g2048_synth_actions would write
+        const StepOut o = NOOP_ACTIONS ? step_board_sel_noop(prev[k], dir_sel(s_dir, action[k] & 3u), action[k] > 3u, rng_draw_lo(k0, k1, id, 0u), tenth)
+                                       : step_board_sel(prev[k], dir_sel(s_dir, action[k] & 3u), rng_draw_lo(k0, k1, id, 0u), tenth);
         Board cur = o.board;
         uint32_t s = sc[k] + o.gain;
         if (AUTO_RESET) {
             if (o.flags & G2048_FLAG_DONE) {
-                cur = fresh_board(rng_draw(e0, e1, id, 0u), rng_draw(e0, e1, id, 1u));
+                cur = fresh_board(rng_draw_lo(e0, e1, id, 0u), rng_draw_lo(e0, e1, id, 1u));
                 s = 0u;
             }
         }
         // B == 1: the lanes past the end of a ragged last block ran the arithmetic on their clamped loads (no exec region around
         // the body: the compiler would sink the loads into it, behind the table's write); they store nothing
-        if (B == 1 && !(full || j < lim)) return;
+        if (B == 1 && !(full || threadIdx.x < lim)) return;
         store_board(bout, j, cur);
         scp[j] = s;
         if (REWARD_F64) rw64[j] = o.reward;
@@ -655,6 +665,19 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     const bool random_actions = (opts & G2048_STEP_RANDOM_ACTIONS) != 0u;
     if (!boards_in || (!actions && !random_actions) || !boards_out || !score_inout || !reward_out || !flags_out)
         return fail(G2048_ERR_ARG, "g2048_step: null pointer");
+    {   // The kernel hashes the low word of a board id and takes the high word's term as a launch constant: a range of ids that
+        // crosses a multiple of 2^32 becomes two launches, cut there (every per-board array is offset by the same number of boards).
+        const uint64_t to_wrap = 0x100000000ull - (board_id_base & 0xffffffffull);
+        if ((uint64_t)n > to_wrap) {
+            const size_t n1 = (size_t)to_wrap, rb = (opts & G2048_STEP_REWARD_F64) ? 8u : 4u;
+            const int rc = step_impl(boards_in, actions, boards_out, score_inout, reward_out, flags_out, seed, step_index, board_id_base, n1,
+                                     opts, stream, keyblock);
+            if (rc != G2048_OK) return rc;
+            return step_impl(static_cast<const char *>(boards_in) + 16u * n1, actions ? actions + n1 : nullptr,
+                             static_cast<char *>(boards_out) + 16u * n1, score_inout + n1, static_cast<char *>(reward_out) + rb * n1,
+                             flags_out + n1, seed, step_index, board_id_base + n1, n - n1, opts, stream, keyblock);
+        }
+    }
     if (random_actions && keyblock) return fail(G2048_ERR_ARG, "g2048_step_dyn: RANDOM_ACTIONS needs the scalar form");
     if (!aligned16(boards_in) || !aligned16(boards_out)) return fail(G2048_ERR_ARG, "g2048_step: board arrays must be 16-byte aligned");
     if (!aligned4(score_inout) || !aligned4(reward_out) || ((opts & G2048_STEP_REWARD_F64) && (reinterpret_cast<uintptr_t>(reward_out) & 7u)))
@@ -673,13 +696,13 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
     const int per_lane = tune == 1 ? 1 : tune == 2 ? 2 : (n >= ((size_t)1 << 22) ? 2 : kStepBoardsPerLane);
 #define G2048_LAUNCH_STEP(F, A, BB) \
     hipLaunchKernelGGL((step_kernel<F, A, BB, kBlock>), dim3(blocks_for(n, kBlock * BB)), dim3(kBlock), 0, s, n, keyblock, in, actions, \
-                       score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
+                       score_inout, (uint32_t)board_id_base, rng_hi_term(board_id_base), k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
 #define G2048_LAUNCH_STEP_B(F, A) \
     do { if (per_lane == 1) G2048_LAUNCH_STEP(F, A, 1); else G2048_LAUNCH_STEP(F, A, 2); } while (0)
     if (opts & G2048_STEP_NOOP_ACTIONS) {            // reference semantics for action values outside 0..3 (drop-in class)
         if (random_actions) return fail(G2048_ERR_ARG, "g2048_step: NOOP_ACTIONS needs explicit actions");
 #define G2048_LAUNCH_NOOP(F, A) hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, false, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, \
-                           n, keyblock, in, actions, score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
+                           n, keyblock, in, actions, score_inout, (uint32_t)board_id_base, rng_hi_term(board_id_base), k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1)
         if (f64 && ar) G2048_LAUNCH_NOOP(true, true); else if (f64) G2048_LAUNCH_NOOP(true, false);
         else if (ar) G2048_LAUNCH_NOOP(false, true); else G2048_LAUNCH_NOOP(false, false);
 #undef G2048_LAUNCH_NOOP
@@ -689,7 +712,7 @@ static int step_impl(const void *boards_in, const uint8_t *actions, void *boards
         const Keys ak = rng_keys(seed, DOM_SYNTH_ACTION, step_index);
 #define G2048_LAUNCH_RANDOM(F, A) \
         hipLaunchKernelGGL((step_kernel<F, A, 1, kBlock, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, s, n, keyblock, in, actions, \
-                           score_inout, board_id_base, k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1, ak.k0, ak.k1)
+                           score_inout, (uint32_t)board_id_base, rng_hi_term(board_id_base), k.k0, k.k1, out, reward_out, flags_out, e.k0, e.k1, ak.k0, ak.k1)
         if (f64 && ar) G2048_LAUNCH_RANDOM(true, true);
         else if (f64) G2048_LAUNCH_RANDOM(true, false);
         else if (ar) G2048_LAUNCH_RANDOM(false, true);

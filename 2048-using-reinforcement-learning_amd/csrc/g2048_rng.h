@@ -32,6 +32,9 @@ G2048_RNG_HD Keys rng_keys(uint64_t seed, uint32_t domain, uint64_t index)
     return Keys{(uint32_t)b, (uint32_t)(b >> 32)};
 }
 
+// the term the high word of a board / game id contributes to a draw (g2048_board.h rng_draw: h += k1 + id_hi * 0x9E3779B1 + ...)
+G2048_RNG_HD uint32_t rng_hi_term(uint64_t id) { return (uint32_t)(id >> 32) * 0x9E3779B1u; }
+
 // ---- sampling without replacement (g2048_minibatch_gather; PPOMemory.sample, agents/ppo_agent.py:21-50) ----------------
 // Sample j of a batch is transition P(j), P a keyed bijection of 0 .. n-1: a four-round Feistel network on 2h bits
 // (2^2h >= n; a Feistel network is a bijection of its 2h-bit domain whatever the round function) walked until it lands

@@ -33,6 +33,8 @@ void hs_rng_keys(uint64_t seed, uint32_t domain, uint64_t index, uint32_t *k0, u
 }
 
 uint32_t hs_rng_draw(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr) { return rng_draw(k0, k1, id, ctr); }
+// the form the step kernel uses: the id's high word folded into the key once per launch, the lane hashes the low word
+uint32_t hs_rng_draw_split(uint32_t k0, uint32_t k1, uint64_t id, uint32_t ctr) { return rng_draw_lo(k0, k1 + rng_hi_term(id), (uint32_t)id, ctr); }
 
 void hs_move(const uint8_t *in, const uint8_t *actions, int agent, uint8_t *out, uint32_t *gain, uint8_t *valid, size_t n)
 {

@@ -822,3 +822,35 @@ def test_step_pieces_as_env_ops_and_drop_in_methods(ops, oracle):
     b = dev(g["board"][:1].copy()); sc = torch.zeros(1, dtype=torch.int32, device=DEV); rec = torch.zeros(80, dtype=torch.uint8, device=DEV)
     with pytest.raises(RuntimeError):
         ops.env_step(b, sc, rec, 1, 0, 0, 0, 6)
+
+
+@pytest.mark.parametrize("id_base,n", [((1 << 32) - 1000, 5000), ((1 << 32) - 256, 70000), ((7 << 32) - 1, 3), ((1 << 33) - 513, 1025)])
+def test_step_across_a_multiple_of_2_to_32_in_the_board_ids(ops, oracle, id_base, n):
+    """The step kernel hashes the low word of a board id and takes the high word's term as a launch constant; g2048_step cuts a
+    launch whose ids cross a multiple of 2^32 in two there. Same results as the oracle's 64-bit ids on both sides of the cut:
+    explicit actions with the f64 reward, in-kernel random actions with auto-reset, and the no-op action form."""
+    b = ops.synth_boards(n, seed=9, id_base=id_base, p_empty=0.4, max_code=6, device=DEV)
+    a = ops.synth_actions(n, seed=9, step_index=4, id_base=id_base, device=DEV)
+    hb, ha = host(b), host(a)
+    sc = torch.full((n,), 12, dtype=torch.int32, device=DEV)
+    out, rw, fl = ops.step(b, a, sc, 9, 4, id_base, reward_f64=True)
+    bo, so, ro, fo = oracle.step_batch(hb, ha, np.full(n, 12, np.uint32), seed=9, step_index=4, id_base=id_base)
+    assert np.array_equal(host(out), bo) and np.array_equal(host(sc).astype(np.uint32), so)
+    assert np.array_equal(host(rw), ro, equal_nan=True) and np.array_equal(host(fl), fo)
+    # in place, f32 reward: the bits of float32(f64 reward)
+    b2, sc2 = b.clone(), torch.full((n,), 12, dtype=torch.int32, device=DEV)
+    _, rw2, fl2 = ops.step(b2, a, sc2, 9, 4, id_base, out=b2)
+    assert torch.equal(b2, out) and torch.equal(sc2, sc) and np.array_equal(host(rw2), ro.astype(np.float32), equal_nan=True)
+    # random actions + auto-reset: what the shard [id_base, id_base + n) of a larger launch computes must not depend on where it was cut
+    sc3, sc4 = torch.zeros(n, dtype=torch.int32, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV)
+    o3, r3, f3 = ops.step(b, None, sc3, 9, 7, id_base, auto_reset=True)
+    half = n // 2
+    o4, r4, f4 = torch.empty_like(o3), torch.empty_like(r3), torch.empty_like(f3)
+    for lo, hi in ((0, half), (half, n)):
+        if hi > lo:
+            ops.step(b[lo:hi].contiguous(), None, sc4[lo:hi], 9, 7, id_base + lo, out=o4[lo:hi], reward=r4[lo:hi], flags=f4[lo:hi], auto_reset=True)
+    assert torch.equal(o3, o4) and torch.equal(sc3, sc4) and torch.equal(f3, f4) and torch.equal(r3.view(torch.int32), r4.view(torch.int32))
+    acts = oracle.synth_actions(n, seed=9, step_index=7, id_base=id_base)
+    bo3, so3, ro3, fo3 = oracle.step_batch(hb, acts, np.zeros(n, np.uint32), seed=9, step_index=7, id_base=id_base, opts=0)
+    live = (fo3 & 1) == 0                                  # boards that did not end: no reset took their place
+    assert np.array_equal(host(o3)[live], bo3[live]) and np.array_equal(host(f3), fo3)

@@ -55,6 +55,14 @@ def test_rng_matches_oracle(hs, oracle):
         hs.hs_rng_keys(C.c_uint64(int(seed)), C.c_uint32(int(dom)), C.c_uint64(int(idx)), C.byref(a), C.byref(b))
         assert (a.value, b.value) == (int(k0), int(k1))
         assert hs.hs_rng_draw(int(k0), int(k1), int(ident), int(ctr)) == int(h)
+    # the split form (high word's term folded into the key, low word hashed: g2048_step's kernel) is the same function of the 64-bit id
+    hs.hs_rng_draw_split.restype = C.c_uint32
+    hs.hs_rng_draw_split.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    rng = np.random.default_rng(8)
+    ids = np.concatenate([rng.integers(0, 2**63, 2000, dtype=np.uint64), np.array([0, 2**32 - 1, 2**32, 2**32 + 1, 2**63 + 5, 2**64 - 1], np.uint64)])
+    for ident in ids:
+        k0, k1, ctr = (int(x) for x in rng.integers(0, 2**32, 3, dtype=np.uint64))
+        assert hs.hs_rng_draw_split(k0, k1, int(ident), ctr) == hs.hs_rng_draw(k0, k1, int(ident), ctr) == oracle.rng_draw(k0, k1, int(ident), ctr)
 
 
 def test_transpose_rot180(hs):
