@@ -468,16 +468,15 @@ G2048_HD uint32_t max_code(const Board &b)
 // edge / total of the reward as an IEEE-754 correctly rounded f64 quotient without the generic division's range
 // handling: both operands are integers below 2^23 (exact in f64, no overflow / underflow / denormal is reachable), so
 // the scaling (v_div_scale_f64 x2) and the special-case fix-up (v_div_fixup_f64) of the compiler's expansion are
-// no-ops here and what remains is that expansion itself: v_rcp_f64, two Newton steps, quotient, residual, final fma.
+// no-ops here; and of that expansion's two Newton steps on the reciprocal ONE is enough for these operands: v_rcp_f64, one
+// Newton step, quotient, residual, final fma give the bits of a / b for every reachable pair -- all 1.76e13 of them were
+// compared on the device (tools/ubench/div_check.hip, profiles/r05_div_check.txt; without any Newton step half of them differ).
 // 0 / 0 (the degenerate all-empty board) gives NaN as a / b does: rcp(0) = inf, fma(-0, inf, 1) = NaN.
-// tools/ubench/div_check.hip compares it with a / b over every operand pair of a range on the device.
 G2048_HD double div_small_ints(double a, double b)
 {
 #if defined(__HIPCC__)
     double y = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-b, y, 1.0);
+    const double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
     const double q = a * y;
     const double r = __builtin_fma(-b, q, a);

@@ -10,6 +10,22 @@
 
 #include "g2048_board.h"
 
+// -DVARIANT_NR=k: check a candidate with k Newton steps on the reciprocal instead of the library's function (round 5: k = 1 passes
+// every pair and became the library's form; k = 0 fails for 47 % of them; k = 2 is the compiler's own expansion)
+#ifdef VARIANT_NR
+namespace g2048 {
+__device__ __forceinline__ double div_variant(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    for (int k = 0; k < VARIANT_NR; ++k) { const double e = __builtin_fma(-b, y, 1.0); y = __builtin_fma(y, e, y); }
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+}
+#define div_small_ints div_variant
+#endif
+
 __global__ void check_kernel(uint32_t lo, uint32_t hi, unsigned long long *mismatch, unsigned long long *pairs)
 {
     unsigned long long bad = 0, cnt = 0;
