@@ -129,6 +129,7 @@ class StepChains:
         per = -(-per // self.ALIGN) * self.ALIGN
         self.bounds = [(lo, min(lo + per, n)) for lo in range(0, max(n, 1), per)]       # fewer than `chains` slices for a small n
         self._side = None
+        self._events = None
         self._open_on = None        # the stream the open chains were forked from; None = joined
         self._held = []             # inputs of open chains, kept alive until the join
 
@@ -159,10 +160,25 @@ class StepChains:
             self.join()             # the caller switched streams with chains open: close them where they were opened
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in self.bounds[1:]]
-        for s in self._side:
-            s.wait_stream(cur)
+        self._order(cur, self._side)
         self._open_on = cur
         return cur
+
+    def _order(self, first, then):
+        """Every stream of `then` waits for what `first` holds now -- with events this object keeps (Stream.wait_stream makes a
+        new one per call: ~10 us of host time each, which a fork + join per step pays twice)."""
+        if self._events is None:
+            self._events = [torch.cuda.Event() for _ in range(1 + len(self.bounds))]
+        if isinstance(then, list):
+            ev = self._events[0]
+            ev.record(first)
+            for s in then:
+                s.wait_event(ev)
+        else:                       # `first` is a list here: `then` waits for each of them
+            for k, s in enumerate(first):
+                ev = self._events[1 + k]
+                ev.record(s)
+                then.wait_event(ev)
 
     def stream(self, c):
         """The stream chain c launches on (valid between fork() and join())."""
@@ -171,15 +187,12 @@ class StepChains:
     def fence(self):
         """Open chains wait for everything queued on the current stream so far (inputs produced after the fork)."""
         if self._open_on is not None:
-            cur = torch.cuda.current_stream(self.device)
-            for s in self._side:
-                s.wait_stream(cur)
+            self._order(torch.cuda.current_stream(self.device), self._side)
 
     def join(self):
         """The stream the chains were opened on waits for every chain's last launch. No-op when nothing is open."""
         if self._open_on is not None:
-            for s in self._side:
-                self._open_on.wait_stream(s)
+            self._order(self._side, self._open_on)
             self._open_on = None
             self._held.clear()
 

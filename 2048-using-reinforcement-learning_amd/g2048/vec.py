@@ -43,7 +43,7 @@ class VecGame2048:
     its own on its own stream, ordered only behind the same slice's previous step. Boards are independent, so the result
     is the single launch's bit for bit (draws are keyed by global board id); what changes is the launch form: one
     chain's launch head and drain overlap the other chains' arithmetic, which a single launch per step cannot do
-    (13.2-13.9 -> 10.4-11.9 us per 1 Mi-board step with two chains on two streams). `step(..., join=False)`
+    (12.4 -> 10.2-10.7 us per 1 Mi-board step with two chains on two streams). `step(..., join=False)`
     leaves the chains open across steps -- that is where the overlap comes from; see `step` and `join`.
     """
 
@@ -71,6 +71,21 @@ class VecGame2048:
         self.chain_bounds = self._chains.bounds
         if len(self.chain_bounds) > 1:
             self._chains.keep_alive(self.boards, self._spare, self.scores, self.reward, self.flags)
+        # Launch arguments of step(), prepared once: the state tensors never move (boards / _spare swap roles, nothing is
+        # reallocated), so a step is one foreign call per chain with the action pointer, the step index and the stream filled in --
+        # no tensor checks, no slicing, no stream context in the loop (tools/vec_rate.py).
+        self._fn = L.lib().g2048_step
+        self._opts = (L.STEP_REWARD_F64 if self.reward_f64 else 0) | (L.STEP_AUTO_RESET if self.auto_reset else 0)
+        rb = self.reward.element_size()
+        a, b = self.boards.data_ptr(), self._spare.data_ptr()
+        self._ptr_a = a
+        self._lanes = []
+        for lo, hi in self.chain_bounds:
+            fixed = (self.scores.data_ptr() + 4 * lo, self.reward.data_ptr() + rb * lo, self.flags.data_ptr() + lo)
+            self._lanes.append((lo, hi - lo, (a + 16 * lo, b + 16 * lo), fixed, L.u64(self.id_base + lo)))
+        self._seed64 = L.u64(self.seed)
+        self._done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)      # step()'s `done`: one elementwise launch into a
+        self._done = self._done_u8.view(torch.bool)                                      # buffer of the env (a live view, like `info`)
         self.reset()
 
     # ---- independent sub-batch chains (ops.StepChains) -----------------------------------------------------------------
@@ -106,37 +121,59 @@ class VecGame2048:
     def step(self, actions=None, join=True):
         """actions uint8 (n,), or None for a random playout step (uniform actions drawn inside the kernel, the same ones
         `random_actions()` returns for this step). Returns (boards, reward, done(bool), info) -- tensors, no host sync.
-        info: score, valid_move, highest_tile (as in game_2048.py:206-210).
+        info: score, valid_move, highest_tile (as in game_2048.py:206-210). All four are views of the env's live buffers:
+        read (or clone) them before the next step. Host cost: one foreign call per chain plus one elementwise launch for `done`
+        (tools/vec_rate.py: ~13 us per step() with one chain, the same with two chains and join=False).
 
         chains > 1: one launch per chain, chain c on its own stream behind chain c's previous step. join=True (default)
-        closes the chains before returning: the results are ordered on the current stream like a single launch's.
+        closes the chains before returning: the results are ordered on the current stream like a single launch's -- and every
+        step pays a fork and a join (~35 us per step at 1 Mi boards against ~13 us with one chain: chains only pay with
+        join=False, ~11 us per step).
         join=False leaves them open and returns None: further `step(..., join=False)` calls queue behind their own chain
         only (capture such a loop in a hipGraph, or keep the host ahead of the GPU, and the chains overlap); call `join()`
         before reading `boards` / `reward` / `flags` / `scores` on the current stream. Inputs of an open chain must have been
         queued before the chains were opened, or be handed over with `fence()`."""
-        if len(self.chain_bounds) == 1:
-            ops.step(self.boards, actions, self.scores, self.seed, self.t, self.id_base, out=self._spare,
-                     reward=self.reward, flags=self.flags, reward_f64=self.reward_f64, auto_reset=self.auto_reset)
+        if actions is None:
+            act, opts = 0, self._opts | L.STEP_RANDOM_ACTIONS
         else:
+            if (not isinstance(actions, torch.Tensor) or actions.dtype != torch.uint8 or actions.device != self.boards.device
+                    or actions.dim() != 1 or actions.shape[0] != self.n or not actions.is_contiguous()):
+                L.require_device_tensor(actions, torch.uint8, None, "actions")           # (says what is wrong)
+                raise ValueError("g2048: actions must be a contiguous uint8 tensor of one action per board on the env's device")
+            act, opts = actions.data_ptr(), self._opts
+        src = 0 if self.boards.data_ptr() == self._ptr_a else 1          # which of the two board buffers holds the state
+        many = len(self._lanes) > 1
+        if many:
             if actions is not None:
-                L.require_device_tensor(actions, torch.uint8, None, "actions")
-                if actions.shape[0] != self.n:
-                    raise ValueError("g2048: actions length must equal the number of boards")
                 self._chains.hold(actions)
             self._chains.fork()
-            for c, (lo, hi) in enumerate(self.chain_bounds):
-                with torch.cuda.stream(self._chains.stream(c)):
-                    ops.step(self.boards[lo:hi], None if actions is None else actions[lo:hi], self.scores[lo:hi], self.seed, self.t,
-                             self.id_base + lo, out=self._spare[lo:hi], reward=self.reward[lo:hi], flags=self.flags[lo:hi],
-                             reward_f64=self.reward_f64, auto_reset=self.auto_reset)
+        t = L.u64(self.t)
+        if torch.cuda.current_device() != self._dev_index():
+            with torch.cuda.device(self.device):
+                rc = self._launch(act, opts, src, t, many)
+        else:
+            rc = self._launch(act, opts, src, t, many)
+        if rc != L.OK:
+            L.check(rc)
         self.boards, self._spare = self._spare, self.boards
         self.t += 1
-        if not join and len(self.chain_bounds) > 1:
+        if not join and many:
             return None
         self.join()
-        done = (self.flags & L.FLAG_DONE).bool()
-        info = _StepInfo(self)
-        return self.boards, self.reward, done, info
+        torch.bitwise_and(self.flags, L.FLAG_DONE, out=self._done_u8)
+        return self.boards, self.reward, self._done, _StepInfo(self)
+
+    def _dev_index(self):
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    def _launch(self, act, opts, src, t, many):
+        fn, seed = self._fn, self._seed64
+        for c, (lo, n, boards, fixed, id_base) in enumerate(self._lanes):
+            stream = self._chains.stream(c).cuda_stream if many else torch.cuda.current_stream(self.device).cuda_stream
+            rc = fn(boards[src], (act + lo) if act else None, boards[1 - src], fixed[0], fixed[1], fixed[2], seed, t, id_base, n, opts, stream)
+            if rc != L.OK:
+                return rc
+        return L.OK
 
     def random_playout(self, steps, want_rewards=False, want_flags=False, want_episodes=False):
         """`steps` random-playout steps of every board in ONE launch (g2048_step_many: the boards stay in registers between
