@@ -854,3 +854,25 @@ def test_step_across_a_multiple_of_2_to_32_in_the_board_ids(ops, oracle, id_base
     bo3, so3, ro3, fo3 = oracle.step_batch(hb, acts, np.zeros(n, np.uint32), seed=9, step_index=7, id_base=id_base, opts=0)
     live = (fo3 & 1) == 0                                  # boards that did not end: no reset took their place
     assert np.array_equal(host(o3)[live], bo3[live]) and np.array_equal(host(f3), fo3)
+
+
+@pytest.mark.parametrize("tune", [0, 2])
+@pytest.mark.parametrize("n", [1, 65, 257, 1000, 70001])
+def test_step_writes_nothing_past_the_last_board(ops, n, tune):
+    """The lanes past the end of a ragged last block load a clamped index and compute like everybody else (no exec region around
+    the body); they must store nothing: every output array carries a sentinel tail that has to survive, in place and out of place."""
+    pad = 600
+    boards = ops.synth_boards(n + pad, seed=3, device=DEV)
+    acts = ops.synth_actions(n + pad, seed=3, device=DEV)
+    for in_place in (False, True):
+        src = boards.clone()
+        out = src if in_place else torch.full_like(src, 0xAB)
+        if in_place:
+            out[n:] = 0xAB
+        sc = torch.full((n + pad,), 0x55AA55, dtype=torch.int32, device=DEV)
+        rw = torch.full((n + pad,), -12345.0, dtype=torch.float32, device=DEV)
+        fl = torch.full((n + pad,), 0xEE, dtype=torch.uint8, device=DEV)
+        ops.step(src[:n], acts[:n], sc[:n], 3, 1, 0, out=out[:n], reward=rw[:n], flags=fl[:n], tune=tune)
+        torch.cuda.synchronize()
+        assert bool((out[n:] == 0xAB).all()) and bool((sc[n:] == 0x55AA55).all()) and bool((rw[n:] == -12345.0).all()) and bool((fl[n:] == 0xEE).all())
+        assert not bool((fl[:n] == 0xEE).all()) or n < 3          # (and the boards in range were written)
