@@ -253,11 +253,11 @@ __global__ __launch_bounds__(BLOCK) void step_many_kernel(const uint4 *boards_in
 // (no fill launch), the board and score are updated in place, and ONE 80-byte record receives everything the host mirrors need:
 // the state in the reference's layout (int32 tile values), the score, the flags, the NEXT state's valid-move mask (so that
 // get_valid_moves() is a cache read) and the f64 reward. One wavefront, lane 0 stores.
-struct EnvRecord { int32_t tiles[16]; int32_t score; uint8_t flags, valid_next, pad[2]; double reward; };
+struct EnvRecord { int32_t tiles[16]; int32_t score; uint8_t flags, valid_next; uint16_t token; double reward; };
 static_assert(sizeof(EnvRecord) == G2048_ENV_RECORD_BYTES && offsetof(EnvRecord, reward) == 72, "record layout is part of the ABI");
 
 __global__ __launch_bounds__(64) void env_step_kernel(uint4 *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op,
-                                                     EnvRecord *record, uint32_t k0, uint32_t k1, uint64_t id)
+                                                     EnvRecord *record, uint32_t k0, uint32_t k1, uint64_t id, uint32_t token)
 {
     const uint4 bv = board_inout[0];
     Board cur = {{bv.x, bv.y, bv.z, bv.w}};
@@ -298,8 +298,12 @@ __global__ __launch_bounds__(64) void env_step_kernel(uint4 *board_inout, uint32
         tiles[r] = make_int4(tile(x & 0xffu), tile((x >> 8) & 0xffu), tile((x >> 16) & 0xffu), tile(x >> 24));
     }
     record->score = (int32_t)sc;
-    record->flags = (uint8_t)flags; record->valid_next = (uint8_t)valid_next; record->pad[0] = record->pad[1] = 0;
+    record->flags = (uint8_t)flags; record->valid_next = (uint8_t)valid_next;
     record->reward = reward;
+    // the caller's token LAST, behind a system-scope fence: a host polling it on a pinned record has the whole record when it
+    // sees the token, without a stream synchronisation (whose wake-up costs more than this launch)
+    __threadfence_system();
+    __hip_atomic_store(&record->token, (uint16_t)token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------ recorded games --
@@ -783,10 +787,13 @@ int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, ui
 {
     if (!board_inout || !score_inout || !record_out) return fail(G2048_ERR_ARG, "g2048_env_step: null pointer");
     if (!aligned16(board_inout) || !aligned4(score_inout) || !aligned16(record_out)) return fail(G2048_ERR_ARG, "g2048_env_step: misaligned pointer");
+    const uint32_t token = (op >> G2048_ENV_TOKEN_SHIFT) & 0xffffu;
+    if (op >> (G2048_ENV_TOKEN_SHIFT + 16)) return fail(G2048_ERR_ARG, "g2048_env_step: unknown op bits 0x%x", op);
+    op &= (1u << G2048_ENV_TOKEN_SHIFT) - 1u;
     if (op > G2048_ENV_OP_MOVE_AGENT) return fail(G2048_ERR_ARG, "g2048_env_step: unknown op %u", op);
     const Keys k = rng_keys(seed, op == G2048_ENV_OP_RESET ? DOM_RESET : DOM_STEP, index);
     hipLaunchKernelGGL(env_step_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint4 *>(board_inout),
-                       score_inout, action, op, static_cast<EnvRecord *>(record_out), k.k0, k.k1, board_id);
+                       score_inout, action, op, static_cast<EnvRecord *>(record_out), k.k0, k.k1, board_id, token);
     return check_launch("g2048_env_step");
 }
 

@@ -46,6 +46,8 @@ class Game2048Env:
         self._record_on_host = (record or self.RECORD) == "host"
         self._rec = self._host if self._record_on_host else torch.zeros(L.ENV_RECORD_BYTES, dtype=torch.uint8, device=self.device)
         self._h = self._host.numpy()
+        self._h16 = self._h.view(np.uint16)         # [35] = bytes 70..71: the token the kernel writes last
+        self._tok = 0
         self._t = 0
         self._epoch = 0
         self._spawns = 0            # add_new_tile() calls made directly (their draws are a stream of their own)
@@ -75,12 +77,24 @@ class Game2048Env:
         self._scores.fill_(int(value))
 
     def _run(self, op, index, action=0):
-        """One g2048_env_step launch + one synchronisation; refreshes the host mirrors. Returns (flags, reward)."""
-        ops.env_step(self._boards, self._scores, self._rec, self.seed, index, 0, action, op)
-        stream = torch.cuda.current_stream(self.device)
-        if not self._record_on_host:
+        """One g2048_env_step launch and the wait for its record; refreshes the host mirrors. Returns (flags, reward).
+        With the record in pinned host memory the wait is a poll of the record's token (written last by the kernel, behind a
+        system-scope fence): no stream synchronisation, whose wake-up alone costs more than the launch."""
+        if self._record_on_host:
+            tok = self._tok = self._tok % 65535 + 1
+            ops.env_step(self._boards, self._scores, self._rec, self.seed, index, 0, action, op | (tok << L.ENV_TOKEN_SHIFT))
+            h16, spins = self._h16, 0
+            while h16[35] != tok:
+                spins += 1
+                if spins > 2000000:         # (~1 s: something is wrong with the launch -- let the runtime say what)
+                    torch.cuda.current_stream(self.device).synchronize()
+                    if h16[35] != tok:
+                        raise RuntimeError("g2048: the env record never arrived")
+        else:
+            ops.env_step(self._boards, self._scores, self._rec, self.seed, index, 0, action, op)
+            stream = torch.cuda.current_stream(self.device)
             self._host.copy_(self._rec, non_blocking=True)
-        stream.synchronize()
+            stream.synchronize()
         h = self._h
         self._board_np = h[0:64].view(np.int32).reshape(4, 4).copy()
         self._score = np.int32(h[64:68].view(np.int32)[0])

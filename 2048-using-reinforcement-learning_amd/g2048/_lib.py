@@ -28,6 +28,7 @@ KEYBLOCK_WORDS = 16
 ROLLOUT_OBS_SHIFT, OBS_F32, OBS_F16, OBS_BF16 = 4, 0, 1, 2
 SEEN_SLOT_BYTES = 32
 ENV_RECORD_BYTES, ENV_OP_STEP, ENV_OP_RESET, ENV_OP_PEEK, ENV_OP_MOVE, ENV_OP_SPAWN, ENV_OP_MOVE_AGENT = 80, 0, 1, 2, 3, 4, 5
+ENV_TOKEN_SHIFT = 8
 
 _vp, _u64, _sz, _u32, _int = C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int
 SIGNATURES = {

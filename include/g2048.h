@@ -283,7 +283,10 @@ G2048_API int g2048_replay_games(const void *boards0, const uint32_t *score0_or_
  * of pinned, device-visible host memory, 16-byte aligned -- receives everything the host mirrors of the env need, so that an
  * iteration costs one launch and one copy: [0,64) the state as int32 tile values (get_state, :50-57), [64,68) int32 score,
  * [68] the flags byte (DONE / VALID / max code), [69] the valid-move mask of the NEW state (get_valid_moves, :69-95, for the
- * next iteration), [72,80) the f64 reward (:212-277; 0.0 for every op but STEP).
+ * next iteration), [70,72) a 16-bit token, [72,80) the f64 reward (:212-277; 0.0 for every op but STEP). The token is bits
+ * 8..23 of `op` (G2048_ENV_TOKEN_SHIFT; 0 if the caller passes a bare op) and is written LAST, behind a system-scope fence: a host
+ * that passes a fresh non-zero token and polls [70,72) of a pinned record has the complete record when it reads the token back
+ * -- no stream synchronisation in the loop (the drop-in Game2048Env does this: ~2x the iterations per second).
  * The pieces of a step as ops of their own (the reference's methods of the same names, for callers that drive them directly):
  * op MOVE = Game2048Env._execute_move(action) (:97-114; action 0 is _move_left, :116-168): the slide / merge alone -- score +=
  * merged tiles, no spawn; flags: VALID = the board changed, DONE = is_game_over() of the result. op MOVE_AGENT = the same with
@@ -298,6 +301,7 @@ G2048_API int g2048_replay_games(const void *boards0, const uint32_t *score0_or_
 #define G2048_ENV_OP_MOVE  3u
 #define G2048_ENV_OP_SPAWN 4u
 #define G2048_ENV_OP_MOVE_AGENT 5u
+#define G2048_ENV_TOKEN_SHIFT 8        /* op | (token << 8), token 0 .. 65535 */
 G2048_API int g2048_env_step(void *board_inout, uint32_t *score_inout, uint32_t action, uint32_t op, void *record_out, uint64_t seed,
                    uint64_t index, uint64_t board_id, void *stream);
 
