@@ -38,20 +38,52 @@ class BeamSearchAgent:
         self.gradients = [4 + base[:, None] - base[None, :], 7 - base[:, None] - base[None, :]]
         self.corners = [(0, 0), (0, 3), (3, 0), (3, 3)]
 
+    def _lean_buffers(self):
+        """What one decision needs, allocated once: a pinned host block the kernels read the state from and write the answer to
+        (device-visible memory: no copy in either direction), and the packed root on the device.
+        host block: [0,64) int32 tiles in | [64] action out | [65] caller mask in | [68,72) f32 prob out."""
+        self._hostblk = torch.zeros(80, dtype=torch.uint8).pin_memory()
+        self._hb = self._hostblk.numpy()
+        self._hb_tiles = self._hb[0:64].view(np.int32)
+        self._hb_prob = self._hb[68:72].view(np.float32)
+        self._hb_prob_bits = self._hb[68:72].view(np.uint32)
+        self._root = torch.zeros((1, 16), dtype=torch.uint8, device=self.device)
+        base = self._hostblk.data_ptr()
+        self._p_tiles, self._p_action, self._p_mask, self._p_prob = base, base + 64, base + 65, base + 68
+        lib = L.lib()
+        self._f_pack, self._f_beam = lib.g2048_pack_i32, lib.g2048_beam_get_action
+
     def get_action(self, state, valid_moves=None):                                      # reference :71-181
+        """One decision = two launches and no copy: g2048_pack_i32 reads the state from pinned host memory, g2048_beam_get_action
+        writes action and probability back into it, and the host polls the two (each a single store, preset to values no decision
+        produces) instead of synchronising the stream."""
         if self.device.type != "cuda":
             raise RuntimeError("BeamSearchAgent: needs a ROCm device; there is no CPU path")
-        tiles = torch.as_tensor(np.ascontiguousarray(state, dtype=np.int32).reshape(1, 16), device=self.device)
-        roots = ops.pack(tiles)
-        mask = None
+        if getattr(self, "_hostblk", None) is None:
+            self._lean_buffers()
+        hb = self._hb
+        self._hb_tiles[:] = np.asarray(state, dtype=np.int32).reshape(16)
+        hb[64] = 0xFF                               # no decision is action 255 ...
+        self._hb_prob_bits[0] = 0x7FC00001          # ... or this NaN
+        mask_ptr = None
         if valid_moves is not None:
-            m = sum(int(bool(v)) << a for a, v in enumerate(list(valid_moves)[:4]))
-            mask = torch.tensor([m], dtype=torch.uint8, device=self.device)
-        actions, probs = ops.beam_get_action(roots, self.beam_width, self.search_depth, mask,
-                                             self.early_game_threshold, self.mid_game_threshold,
-                                             self.seed, self._calls, 0)
+            hb[65] = sum(int(bool(v)) << a for a, v in enumerate(list(valid_moves)[:4]))
+            mask_ptr = self._p_mask
+        stream = torch.cuda.current_stream(self.device)
+        sp = stream.cuda_stream
+        L.call(self.device, self._f_pack, self._p_tiles, self._root.data_ptr(), 1, sp)
+        L.call(self.device, self._f_beam, self._root.data_ptr(), mask_ptr, self._p_action, self._p_prob, None, int(self.beam_width),
+               int(self.search_depth), int(self.early_game_threshold), int(self.mid_game_threshold), L.u64(self.seed),
+               L.u64(self._calls), 0, 1, 0, sp)
         self._calls += 1
-        return int(actions.item()), float(probs.item())
+        bits, spins = self._hb_prob_bits, 0
+        while hb[64] == 0xFF or bits[0] == 0x7FC00001:
+            spins += 1
+            if spins > 2000000:                     # (~1 s: let the runtime say what is wrong)
+                stream.synchronize()
+                if hb[64] == 0xFF or bits[0] == 0x7FC00001:
+                    raise RuntimeError("g2048: the decision never arrived")
+        return int(hb[64]), float(self._hb_prob[0])
 
     # -- the reference's per-board helpers, for scripts that call them directly (one board, one small launch each) ----------
     def _codes(self, board):
