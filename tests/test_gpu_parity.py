@@ -850,6 +850,11 @@ def test_step_across_a_multiple_of_2_to_32_in_the_board_ids(ops, oracle, id_base
         if hi > lo:
             ops.step(b[lo:hi].contiguous(), None, sc4[lo:hi], 9, 7, id_base + lo, out=o4[lo:hi], reward=r4[lo:hi], flags=f4[lo:hi], auto_reset=True)
     assert torch.equal(o3, o4) and torch.equal(sc3, sc4) and torch.equal(f3, f4) and torch.equal(r3.view(torch.int32), r4.view(torch.int32))
+    # the keys from a device key block (g2048_step_dyn: graph-replayable loops) take the same cut and the same high-word term
+    kb = ops.KeyBlock(9, start=4, device=DEV).advance()
+    sc5 = torch.full((n,), 12, dtype=torch.int32, device=DEV)
+    o5, r5, f5 = ops.step(b, a, sc5, 0, 0, id_base, reward_f64=True, keyblock=kb)
+    assert torch.equal(o5, out) and torch.equal(sc5, sc) and torch.equal(f5, fl) and np.array_equal(host(r5), ro, equal_nan=True)
     acts = oracle.synth_actions(n, seed=9, step_index=7, id_base=id_base)
     bo3, so3, ro3, fo3 = oracle.step_batch(hb, acts, np.zeros(n, np.uint32), seed=9, step_index=7, id_base=id_base, opts=0)
     live = (fo3 & 1) == 0                                  # boards that did not end: no reset took their place
