@@ -27,7 +27,8 @@ scores = torch.zeros(n, dtype=torch.int32, device=dev)
 reward = torch.empty(n, dtype=torch.float32, device=dev)
 flags = torch.empty(n, dtype=torch.uint8, device=dev)
 sc = ops.StepChains(n, 2, dev)
-calls = [ops.PreparedStep(boards[lo:hi], actions[lo:hi], scores[lo:hi], 0x2048, lo, out=out[lo:hi], reward=reward[lo:hi], flags=flags[lo:hi])
+TUNE = int(os.environ.get("TUNE", "0"))          # 0: the library's choice (one board per lane at this size), 2: two boards per lane
+calls = [ops.PreparedStep(boards[lo:hi], actions[lo:hi], scores[lo:hi], 0x2048, lo, out=out[lo:hi], reward=reward[lo:hi], flags=flags[lo:hi], tune=TUNE)
          for lo, hi in sc.bounds]
 sc.keep_alive(boards, actions, out, scores, reward, flags)
 
