@@ -24,6 +24,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(20261005)
 t_end = time.time() + budget
 runs = boards_total = 0
+last_note = time.time()
 while time.time() < t_end:
     n = int(rng.choice([rng.integers(1, 70), rng.integers(1, 2000), rng.integers(1, 300000), 256 * rng.integers(1, 500)]))
     kind = rng.integers(0, 4)
@@ -54,4 +55,7 @@ while time.time() < t_end:
         sys.exit(1)
     runs += 1
     boards_total += n
+    if time.time() - last_note > 30.0:            # (a long silent run is taken for a hung one on the GPU box)
+        print("  .. %d runs, %d board-steps so far" % (runs, boards_total), flush=True)
+        last_note = time.time()
 print("soak_step done: %d runs, %d board-steps, 0 mismatches" % (runs, boards_total))
