@@ -75,18 +75,33 @@ class VecGame2048:
         # reallocated), so a step is one foreign call per chain with the action pointer, the step index and the stream filled in --
         # no tensor checks, no slicing, no stream context in the loop (tools/vec_rate.py).
         self._fn = L.lib().g2048_step
+        self._prepare()
+        self._done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)      # step()'s `done`: one elementwise launch into a
+        self._done = self._done_u8.view(torch.bool)                                      # buffer of the env (a live view, like `info`)
+        self.reset()
+
+    def _prepare(self):
+        """(Re)build the prepared launch arguments from the state tensors as they are now: once in the constructor, and again
+        should a caller have replaced one of them (`env.boards = ...`), which step() notices by the pointers."""
+        for name, t, dt in (("boards", self.boards, torch.uint8), ("scores", self.scores, torch.int32), ("flags", self.flags, torch.uint8)):
+            L.require_device_tensor(t, dt, (16,) if name == "boards" else None, name)
+            if t.shape[0] != self.n:
+                raise ValueError("g2048: %s must hold %d boards" % (name, self.n))
+        L.require_device_tensor(self.reward, torch.float64 if self.reward_f64 else torch.float32, None, "reward")
+        if self._spare.shape != self.boards.shape or self._spare.device != self.boards.device:
+            self._spare = torch.empty_like(self.boards)
         self._opts = (L.STEP_REWARD_F64 if self.reward_f64 else 0) | (L.STEP_AUTO_RESET if self.auto_reset else 0)
         rb = self.reward.element_size()
         a, b = self.boards.data_ptr(), self._spare.data_ptr()
-        self._ptr_a = a
+        self._ptr_a, self._ptr_b = a, b
+        self._ptr_state = (self.scores.data_ptr(), self.reward.data_ptr(), self.flags.data_ptr())
         self._lanes = []
         for lo, hi in self.chain_bounds:
             fixed = (self.scores.data_ptr() + 4 * lo, self.reward.data_ptr() + rb * lo, self.flags.data_ptr() + lo)
             self._lanes.append((lo, hi - lo, (a + 16 * lo, b + 16 * lo), fixed, L.u64(self.id_base + lo)))
         self._seed64 = L.u64(self.seed)
-        self._done_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)      # step()'s `done`: one elementwise launch into a
-        self._done = self._done_u8.view(torch.bool)                                      # buffer of the env (a live view, like `info`)
-        self.reset()
+        if len(self.chain_bounds) > 1:
+            self._chains.keep_alive(self.boards, self._spare, self.scores, self.reward, self.flags)
 
     # ---- independent sub-batch chains (ops.StepChains) -----------------------------------------------------------------
     def fence(self):
@@ -141,7 +156,13 @@ class VecGame2048:
                 L.require_device_tensor(actions, torch.uint8, None, "actions")           # (says what is wrong)
                 raise ValueError("g2048: actions must be a contiguous uint8 tensor of one action per board on the env's device")
             act, opts = actions.data_ptr(), self._opts
-        src = 0 if self.boards.data_ptr() == self._ptr_a else 1          # which of the two board buffers holds the state
+        bp = self.boards.data_ptr()
+        if (bp != self._ptr_a and bp != self._ptr_b) or self._spare.data_ptr() not in (self._ptr_a, self._ptr_b) or \
+                (self.scores.data_ptr(), self.reward.data_ptr(), self.flags.data_ptr()) != self._ptr_state:
+            self.join()
+            self._prepare()              # a state tensor was replaced from outside
+            bp = self.boards.data_ptr()
+        src = 0 if bp == self._ptr_a else 1          # which of the two board buffers holds the state
         many = len(self._lanes) > 1
         if many:
             if actions is not None:

@@ -881,3 +881,21 @@ def test_step_writes_nothing_past_the_last_board(ops, n, tune):
         torch.cuda.synchronize()
         assert bool((out[n:] == 0xAB).all()) and bool((sc[n:] == 0x55AA55).all()) and bool((rw[n:] == -12345.0).all()) and bool((fl[n:] == 0xEE).all())
         assert not bool((fl[:n] == 0xEE).all()) or n < 3          # (and the boards in range were written)
+
+
+def test_vec_env_notices_a_replaced_state_tensor(ops, oracle):
+    """VecGame2048.step launches from arguments prepared once; a caller who replaces `env.boards` / `env.scores` (rather than
+    copying into them) must still get a step of what the env now holds."""
+    from g2048 import VecGame2048
+    n = 5000
+    env = VecGame2048(n, device=DEV, seed=21, id_base=77, chains=2)
+    a = env.random_actions()
+    env.step(a)
+    nb = ops.synth_boards(n, seed=4, device=DEV)
+    env.boards = nb.clone()
+    env.scores = torch.full((n,), 9, dtype=torch.int32, device=DEV)
+    t = env.t
+    b, r, d, info = env.step(a)
+    bo, so, ro, fo = oracle.step_batch(host(nb), host(a), np.full(n, 9, np.uint32), seed=21, step_index=t, id_base=77)
+    assert np.array_equal(host(b), bo) and np.array_equal(host(env.scores).astype(np.uint32), so)
+    assert np.array_equal(host(r), ro.astype(np.float32), equal_nan=True) and np.array_equal(host(d), (fo & 1).astype(bool))
