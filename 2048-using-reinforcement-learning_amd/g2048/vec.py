@@ -91,6 +91,10 @@ class VecGame2048:
         if self._spare.shape != self.boards.shape or self._spare.device != self.boards.device:
             self._spare = torch.empty_like(self.boards)
         self._opts = (L.STEP_REWARD_F64 if self.reward_f64 else 0) | (L.STEP_AUTO_RESET if self.auto_reset else 0)
+        # chains of at least 256 Ki boards: two boards per lane (G2048_STEP_TUNE 2), so that the chains' launches -- 4 wavefronts per
+        # SIMD each -- are resident together instead of taking turns; smaller chains keep the library's choice
+        if len(self.chain_bounds) > 1 and min(hi - lo for lo, hi in self.chain_bounds) >= (1 << 18):
+            self._opts |= 2 << 8
         rb = self.reward.element_size()
         a, b = self.boards.data_ptr(), self._spare.data_ptr()
         self._ptr_a, self._ptr_b = a, b

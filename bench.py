@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay")
     ap.add_argument("--chains", type=int, default=2,
                     help="a step = this many independent sub-batch launches on parallel hipGraph branches (1 = one launch per step)")
+    ap.add_argument("--chain-tune", type=int, default=-1, help="boards per lane inside a chain: 1 or 2 (default 2); 0 = the library's choice by size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-beam", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
@@ -253,8 +254,12 @@ def main():
     # VecGame2048(chains=C)): chain c's step t+1 is ordered behind chain c's step t only, so one chain's launch head and drain
     # overlap the other's arithmetic. Same kernel, same bytes, same results as one launch per step (checked below).
     sc = ops.StepChains(n, max(1, args.chains), dev)
+    # (inside a chain a lane takes two boards, G2048_STEP_TUNE 2: a 512 Ki-board launch is then 4 wavefronts per SIMD, so both chains'
+    # launches are resident together instead of taking turns at the 8 slots -- 9.3 against 10.6 us per step in steady state, 1-2 % at
+    # K = 20; same kernel arithmetic, same results: profiles/r05_chains_launch_forms.txt, section 10)
+    chain_tune = (args.chain_tune if args.chain_tune >= 0 else 2) if max(1, args.chains) > 1 else 0
     chain_calls = [ops.PreparedStep(boards[lo:hi], actions[lo:hi], scores[lo:hi], SEED, id_base + lo, out=out[lo:hi],
-                                    reward=reward[lo:hi], flags=flags[lo:hi]) for lo, hi in sc.bounds]
+                                    reward=reward[lo:hi], flags=flags[lo:hi], tune=chain_tune) for lo, hi in sc.bounds]
     if len(sc) > 1:
         sc.keep_alive(boards, actions, out, scores, reward, flags)
 
@@ -441,7 +446,7 @@ def main():
                    "parallelism": "%d shard(s) of 1,048,576 boards, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "step_kernel<false,false,1,256>" + (" x %d sub-batch launches per step" % len(sc) if len(sc) > 1 else ""),
+                     "kernel": ("step_kernel<false,false,2,256> x %d sub-batch launches per step (two boards per lane inside a chain)" % len(sc)) if len(sc) > 1 else "step_kernel<false,false,1,256>",
                      "kernel_us": kernel_s * 1e6,
                      "kernel_us_is": ("one whole-batch STEP (all %d sub-batch launches, which overlap): event pair / K. A single sub-batch "
                                       "launch lasts longer than its share of this (tools/chains_wave_timeline.py, profiles/r05_chains_*), "
