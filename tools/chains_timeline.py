@@ -5,6 +5,7 @@ size (grid), the average duration of one launch, the time from the first start t
     python tools/chains_timeline.py <rocprofv3 output dir> [--dump N]
 """
 import csv
+import re
 import glob
 import os
 import sys
@@ -18,9 +19,12 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=
         if "step_kernel" not in row.get("Kernel_Name", ""):
             continue
         grid = int(row.get("Grid_Size") or row.get("Grid_Size_X") or 0)
-        if grid < (1 << 18):            # only the headline-sized launches (sub-batch chains and whole batches)
+        # boards of the launch = threads x boards per lane (the kernel's third template argument: step_kernel<F64, RESET, B, BLOCK, ..>)
+        m = re.search(r"step_kernel<[^,]+,[^,]+,\s*(\d+)\s*,", row["Kernel_Name"])
+        boards = grid * (int(m.group(1)) if m else 1)
+        if boards < (1 << 18):          # only the headline-sized launches (sub-batch chains and whole batches)
             continue
-        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), grid, row.get("Queue_Id", "?"), row["Kernel_Name"]))
+        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), boards, row.get("Queue_Id", "?"), row["Kernel_Name"]))
 rows.sort()
 if not rows:
     sys.exit("no step_kernel launches in " + d)
@@ -50,7 +54,7 @@ for b in bursts:
             busy2 += t - t_prev
         depth += dlt
         t_prev = t
-    steps = sum(r[2] for r in b) / float(1 << 20)          # one lane per board: grid size (threads) = boards of the launch
+    steps = sum(r[2] for r in b) / float(1 << 20)          # r[2] = boards of the launch
     by[(tuple(grids), len(queues))].append((span / 1e3 / steps, sum(r[1] - r[0] for r in b) / len(b) / 1e3, 100.0 * busy1 / span,
                                              100.0 * busy2 / span, len(b)))
 print("%d step_kernel launches of >= 262,144 boards in %d bursts (%s)" % (len(rows), len(bursts), d))
